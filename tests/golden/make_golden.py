@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference in this container.
+
+Run (build container only -- the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference/src python tests/golden/make_golden.py
+
+The reference (omarkhursheed/whisper-sae @ /root/reference) ships no golden vectors, KATs or
+``.pt`` fixtures for its SAE path: its tests are property tests on random data.
+So the oracle is pinned with outputs of the reference itself, produced here.  Inputs and weights
+come from ``oracle/synth.py`` (integer counter generator, version-proof) and are loaded into the
+reference modules with ``load_state_dict``; only the reference's *outputs* are stored.  Everything
+written is data (npz / json): no reference source text is copied anywhere.
+
+Golden sets (SURVEY.md row C list):
+  G1 forward @ cfg2 dims      G2 gradients            G3 one SAETrainer.train_step
+  G4 20-step trajectory       G5 LR schedule          G6 dead-feature tracking
+  G7 resample_dead_features   G8 ReLUSAE fwd/grads    G9 API bookkeeping (keys, batch forms)
+"""
+
+from __future__ import annotations
+
+import json
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parents[1]))
+
+from oracle import synth  # noqa: E402
+
+from whisper_sae.config import TrainingConfig  # noqa: E402  (reference)
+from whisper_sae.sae.model import ReLUSAE, TopKSAE  # noqa: E402  (reference)
+from whisper_sae.sae.training import SAETrainer  # noqa: E402  (reference)
+
+torch.set_num_threads(4)
+
+
+def load_weights(model, w):
+    sd = model.state_dict()
+    for k_, v in w.items():
+        sd[k_] = torch.from_numpy(np.array(v))
+    model.load_state_dict(sd)
+
+
+def sample_positions(shape, n, seed):
+    total = int(np.prod(shape))
+    pos = (synth.counter_u64(n, seed, 99) % np.uint64(total)).astype(np.int64)
+    return pos
+
+
+def sd_numpy(model):
+    return {k_: v.detach().cpu().numpy().copy() for k_, v in model.state_dict().items()}
+
+
+def g1_g2_g3():
+    D, H, K, B = 384, 3072, 32, 64
+    w = synth.sae_weights(D, H, seed=42, bf16=True, b_pre_scale=0.1)
+    x = synth.activations(B, D, seed=42, stream=1, bf16=True)
+    torch.manual_seed(0)
+    m = TopKSAE(D, H, k=K, dead_feature_threshold=1000)
+    load_weights(m, w)
+    m.train()
+    xt = torch.from_numpy(x)
+    # pre-activations for the margin check (same arithmetic as model.py:108-111)
+    with torch.no_grad():
+        pre = m.encoder(xt - m.b_pre).numpy()
+    margin = synth.topk_margin(pre, K)
+    assert margin.min() > 1e-5, f"fixture has a near-tie at the k/k+1 boundary: {margin.min()}"
+    out = m(xt)
+    vals, idx = torch.topk(torch.from_numpy(pre), K, dim=-1)
+    hid = out.hidden.detach().numpy()
+    # the reference's hidden must be exactly the scatter of relu(topk)
+    chk = np.zeros_like(hid)
+    np.put_along_axis(chk, idx.numpy(), np.maximum(vals.numpy(), 0), axis=1)
+    assert np.array_equal(chk, hid)
+    out.loss.backward()
+    grads = {"W_e": m.encoder.weight.grad, "b_e": m.encoder.bias.grad, "W_d": m.decoder.weight.grad,
+             "b_d": m.decoder.bias.grad, "b_pre": m.b_pre.grad}
+    grads = {k_: v.detach().numpy().copy() for k_, v in grads.items()}
+    pos_e = sample_positions((H, D), 1024, 7)
+    pos_d = sample_positions((D, H), 1024, 8)
+    np.savez_compressed(
+        HERE / "g1_forward_cfg2.npz",
+        dims=np.array([D, H, K, B]), seed=np.array([42]), b_pre_scale=np.array([0.1]),
+        idx=idx.numpy().astype(np.int16), vals=vals.numpy(), recon=out.reconstructed.detach().numpy(),
+        loss=np.float32(out.loss.item()), l0=np.float32(out.l0.item()), min_margin=np.float64(margin.min()),
+        last_activated=m.feature_last_activated.numpy().copy(), step_count=np.int64(m.step_count.item()),
+    )
+    np.savez_compressed(
+        HERE / "g2_grads_cfg2.npz",
+        norms=np.array([np.sqrt((grads[n].astype(np.float64) ** 2).sum()) for n in ("W_e", "b_e", "W_d", "b_d", "b_pre")]),
+        b_e=grads["b_e"], b_d=grads["b_d"], b_pre=grads["b_pre"],
+        pos_e=pos_e, W_e_samples=grads["W_e"].reshape(-1)[pos_e],
+        pos_d=pos_d, W_d_samples=grads["W_d"].reshape(-1)[pos_d],
+    )
+
+    # G3: one full SAETrainer.train_step from the same start (fresh model: dead counters at 0)
+    m2 = TopKSAE(D, H, k=K, dead_feature_threshold=1000)
+    load_weights(m2, w)
+    cfg = TrainingConfig(batch_size=B, learning_rate=1e-4, weight_decay=0.0, epochs=3, warmup_steps=100,
+                         gradient_clip=1.0, use_amp=True, checkpoint_every=2, seed=42, num_workers=0)
+    with tempfile.TemporaryDirectory() as td:
+        tr = SAETrainer(m2, cfg, device="cpu", run_dir=Path(td))
+        tr.setup_scheduler(35157)
+        lr0 = tr.optimizer.param_groups[0]["lr"]
+        met = tr.train_step(torch.from_numpy(x))
+        # also: the tuple / list batch forms give the same step (G9)
+        met_t = tr.train_step((torch.from_numpy(x),))
+        met_l = tr.train_step([torch.from_numpy(x)])
+    # re-run a single step on a fresh copy for the post-step-1 parameter values
+    m3 = TopKSAE(D, H, k=K, dead_feature_threshold=1000)
+    load_weights(m3, w)
+    with tempfile.TemporaryDirectory() as td:
+        tr3 = SAETrainer(m3, cfg, device="cpu", run_dir=Path(td))
+        tr3.setup_scheduler(35157)
+        met3 = tr3.train_step(torch.from_numpy(x))
+        ck = tr3.save_checkpoint("c.pt")
+        ck_keys = sorted(torch.load(ck, weights_only=False).keys())
+        opt_sd = tr3.optimizer.state_dict()
+    sd = sd_numpy(m3)
+    total_norm = float(np.sqrt(sum((grads[n].astype(np.float64) ** 2).sum() for n in grads)))
+    np.savez_compressed(
+        HERE / "g3_train_step_cfg2.npz",
+        lr0=np.float64(lr0), loss=np.float64(met3.loss), l0=np.float64(met3.l0),
+        dead_ratio=np.float64(met3.dead_feature_ratio), lr_after=np.float64(met3.learning_rate),
+        step=np.int64(met3.step), grad_total_norm=np.float64(total_norm),
+        b_e=sd["encoder.bias"], b_d=sd["decoder.bias"], b_pre=sd["b_pre"],
+        pos_e=pos_e, W_e_samples=sd["encoder.weight"].reshape(-1)[pos_e],
+        pos_d=pos_d, W_d_samples=sd["decoder.weight"].reshape(-1)[pos_d],
+        W_e_norm=np.float64(np.sqrt((sd["encoder.weight"].astype(np.float64) ** 2).sum())),
+        W_d_colnorm_minmax=np.array([np.linalg.norm(sd["decoder.weight"], axis=0).min(),
+                                     np.linalg.norm(sd["decoder.weight"], axis=0).max()]),
+        losses_3steps=np.array([met.loss, met_t.loss, met_l.loss]),
+        lrs_3steps=np.array([met.learning_rate, met_t.learning_rate, met_l.learning_rate]),
+    )
+    api = {
+        "state_dict_keys": list(m3.state_dict().keys()),
+        "state_dict_shapes": {k_: list(v.shape) for k_, v in m3.state_dict().items()},
+        "state_dict_dtypes": {k_: str(v.dtype) for k_, v in m3.state_dict().items()},
+        "checkpoint_keys": ck_keys,
+        "optimizer_param_group_keys": sorted(opt_sd["param_groups"][0].keys()),
+        "optimizer_state_keys": sorted(opt_sd["state"][0].keys()),
+        "metrics_fields": list(met3.__dataclass_fields__.keys()),
+    }
+    (HERE / "g9_api.json").write_text(json.dumps(api, indent=1))
+
+
+def g4_trajectory():
+    D, H, K, B, STEPS = 64, 256, 8, 16, 20
+    w = synth.sae_weights(D, H, seed=7, bf16=False, b_pre_scale=0.05)
+    xs = synth.activations(B * STEPS, D, seed=7, stream=2, bf16=False).reshape(STEPS, B, D)
+    m = TopKSAE(D, H, k=K, dead_feature_threshold=5)
+    load_weights(m, w)
+    cfg = TrainingConfig(batch_size=B, learning_rate=1e-3, weight_decay=0.01, epochs=1, warmup_steps=5,
+                         gradient_clip=1.0, use_amp=False, num_workers=0)
+    losses, lrs, dead, margins = [], [], [], []
+    with tempfile.TemporaryDirectory() as td:
+        tr = SAETrainer(m, cfg, device="cpu", run_dir=Path(td))
+        tr.setup_scheduler(STEPS)
+        for s in range(STEPS):
+            with torch.no_grad():
+                pre = m.encoder(torch.from_numpy(xs[s]) - m.b_pre).numpy()
+            margins.append(synth.topk_margin(pre, K).min())
+            lrs.append(tr.optimizer.param_groups[0]["lr"])
+            met = tr.train_step(torch.from_numpy(xs[s]))
+            losses.append(met.loss)
+            dead.append(met.dead_feature_ratio)
+        opt = tr.optimizer.state_dict()
+    assert min(margins) > 1e-4, f"trajectory has a near-tie: {min(margins)}"
+    sd = sd_numpy(m)
+    np.savez_compressed(
+        HERE / "g4_trajectory_small.npz",
+        dims=np.array([D, H, K, B, STEPS]), losses=np.array(losses, dtype=np.float64),
+        lrs=np.array(lrs, dtype=np.float64), dead=np.array(dead, dtype=np.float64),
+        min_margin=np.float64(min(margins)),
+        W_e=sd["encoder.weight"], b_e=sd["encoder.bias"], W_d=sd["decoder.weight"], b_d=sd["decoder.bias"],
+        b_pre=sd["b_pre"], last_activated=sd["feature_last_activated"], step_count=sd["step_count"],
+        exp_avg_We=opt["state"][1]["exp_avg"].numpy(), exp_avg_sq_We=opt["state"][1]["exp_avg_sq"].numpy(),  # parameters() order: b_pre, enc.W, enc.b, dec.W, dec.b
+    )
+
+
+def g5_lr():
+    out = {}
+    for name, (total, warm, lr) in {"cfg1": (35157, 100, 1e-4), "short": (50, 1000, 1e-3),
+                                    "nowarm": (40, 0, 3e-4), "tiny": (9, 100, 1e-4)}.items():
+        m = TopKSAE(32, 64, k=4)
+        cfg = TrainingConfig(learning_rate=lr, warmup_steps=warm, use_amp=False, num_workers=0)
+        with tempfile.TemporaryDirectory() as td:
+            tr = SAETrainer(m, cfg, device="cpu", run_dir=Path(td))
+            tr.setup_scheduler(total)
+            n = min(total, 400)
+            vals = []
+            for _ in range(n):
+                vals.append(tr.optimizer.param_groups[0]["lr"])
+                tr.optimizer.step()
+                tr.scheduler.step()
+        out[name] = {"total": total, "warmup_cfg": warm, "lr": lr, "values": vals}
+    (HERE / "g5_lr_schedule.json").write_text(json.dumps(out))
+
+
+def g6_dead():
+    # the reference's own "4 alive of 128 after 60 steps" scenario (tests/test_sae_model.py:251-294)
+    D, H, K = 32, 128, 4
+    w = synth.sae_weights(D, H, seed=999, bf16=False)
+    x = synth.activations(1, D, seed=999, stream=3, bf16=False)
+    m = TopKSAE(D, H, k=K, dead_feature_threshold=50)
+    load_weights(m, w)
+    m.train()
+    r0 = m.get_dead_feature_ratio()
+    for _ in range(60):
+        m(torch.from_numpy(x))
+    np.savez_compressed(
+        HERE / "g6_dead_tracking.npz", dims=np.array([D, H, K]), ratio0=np.float64(r0),
+        ratio60=np.float64(m.get_dead_feature_ratio()), alive=np.int64((~m.get_dead_features()).sum().item()),
+        last_activated=m.feature_last_activated.numpy().copy(), step_count=np.int64(m.step_count.item()),
+    )
+
+
+def g7_resample():
+    D, H, K, B = 64, 256, 8, 24
+    w = synth.sae_weights(D, H, seed=5, bf16=False, b_pre_scale=0.05)
+    x = synth.activations(B, D, seed=5, stream=4, bf16=False)
+    res = {}
+    for tag, train_mode, num in (("train_all", True, None), ("eval_cap", False, 10), ("train_many", True, None)):
+        m = TopKSAE(D, H, k=K, dead_feature_threshold=20)
+        load_weights(m, w)
+        m.train(train_mode)
+        with torch.no_grad():
+            m.step_count.fill_(100)
+            la = torch.full((H,), 95, dtype=torch.long)
+            n_dead = 52 if tag == "train_many" else 12  # 52 > B: "returns capped count, rewrites B" quirk
+            dead_idx = (synth.counter_u64(400, 5, 50) % np.uint64(H)).astype(np.int64)
+            dead_idx = np.unique(dead_idx)[:n_dead]
+            la[torch.from_numpy(dead_idx)] = 3
+            m.feature_last_activated.copy_(la)
+        ret = m.resample_dead_features(torch.from_numpy(x), num)
+        sd = sd_numpy(m)
+        res[tag] = dict(ret=ret, dead_idx=dead_idx, W_e=sd["encoder.weight"], b_e=sd["encoder.bias"],
+                        W_d=sd["decoder.weight"], last_activated=sd["feature_last_activated"],
+                        step_count=sd["step_count"])
+    flat = {}
+    for tag, d in res.items():
+        for k_, v in d.items():
+            flat[f"{tag}.{k_}"] = np.asarray(v)
+    np.savez_compressed(HERE / "g7_resample.npz", dims=np.array([D, H, K, B]), **flat)
+
+
+def g8_relu():
+    D, H, B = 64, 256, 32
+    w = synth.sae_weights(D, H, seed=11, bf16=False)
+    x = synth.activations(B, D, seed=11, stream=5, bf16=False)
+    m = ReLUSAE(D, H, sparsity_weight=0.01)
+    sd = m.state_dict()
+    for k_ in ("encoder.weight", "encoder.bias", "decoder.weight", "decoder.bias"):
+        sd[k_] = torch.from_numpy(w[k_])
+    m.load_state_dict(sd)
+    out = m(torch.from_numpy(x))
+    out.loss.backward()
+    np.savez_compressed(
+        HERE / "g8_relu.npz", dims=np.array([D, H, B]), loss=np.float32(out.loss.item()),
+        mse=np.float32(out.reconstruction_loss.item()), l1=np.float32(out.sparsity_loss.item()),
+        l0=np.float32(out.l0.item()), recon=out.reconstructed.detach().numpy(),
+        hidden_nnz=np.int64((out.hidden > 0).sum().item()),
+        dW_e=m.encoder.weight.grad.numpy(), db_e=m.encoder.bias.grad.numpy(),
+        dW_d=m.decoder.weight.grad.numpy(), db_d=m.decoder.bias.grad.numpy(),
+    )
+
+
+if __name__ == "__main__":
+    g1_g2_g3()
+    g4_trajectory()
+    g5_lr()
+    g6_dead()
+    g7_resample()
+    g8_relu()
+    for p in sorted(HERE.glob("g*")):
+        print(p.name, p.stat().st_size)
