@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""SAE train-step throughput on MI355X: activations/sec through the TopK-SAE train step
+(d = 384 -> 3072, k = 32), BASELINE.json's metric on its config 2 (1 GPU) / 3 (N GPUs).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one full ``SAETrainer.train_step`` on a batch of B activation rows already resident in the
+on-device ring buffer: stage + encode GEMM + TopK + sparse decode/MSE + weight-gradient GEMMs +
+(RCCL all-reduce for N > 1) + clip + AdamW + decoder renorm + dead-feature scan.  Weak scaling:
+B per GPU fixed, global batch = N * B.  Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for _p in (str(ROOT), str(ROOT / "whisper-sae_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+D_MODEL, HIDDEN, TOPK = 384, 3072, 32
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(batch: int, budget_s: float = 20.0) -> dict:
+    """Reference-semantics CPU train step (oracle/torch_step.py, kind "port") on the host cores."""
+    import numpy as np
+    import torch
+
+    from oracle import synth
+    from oracle.torch_step import TorchCPUStep
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    w = synth.sae_weights(D_MODEL, HIDDEN, seed=42, bf16=False)
+    step = TorchCPUStep(w, TOPK, lr=1e-4, weight_decay=0.0, max_norm=1.0)
+    x = torch.from_numpy(synth.activations(batch, D_MODEL, seed=42, stream=0, bf16=False))
+    step.step(x)  # warm-up (allocations, thread pool)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step.step(x)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": batch * n / el, "unit": "activations/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of B={batch} (384->3072, k=32, fp32, torch {torch.__version__} CPU, "
+                      f"{el:.1f} s); oracle/torch_step.py restates training.py:161-217"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=16384, help="activation rows per GPU per step")
+    ap.add_argument("--ring-rows", type=int, default=1 << 22)
+    ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel (adds event overhead)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from whisper_sae import _native as N
+    from whisper_sae.config import TrainingConfig
+    from whisper_sae.data import ActivationRing, RingLoader
+    from whisper_sae.sae.model import TopKSAE
+    from whisper_sae.sae.training import SAETrainer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    B = args.batch
+    torch.manual_seed(42)  # same initial weights on every rank (scripts/train.py:84-90 seeds before create_sae)
+    model = TopKSAE(D_MODEL, HIDDEN, k=TOPK)
+    cfg = TrainingConfig(batch_size=B, learning_rate=1e-4, weight_decay=0.0, warmup_steps=1000, gradient_clip=1.0,
+                         use_amp=(args.precision == "bf16"), num_workers=0, seed=42)
+    trainer = SAETrainer(model, cfg, device=device, run_dir=ROOT / "gpurun_out" / f"bench_rank{rank}")
+    ring_dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
+    ring = ActivationRing(args.ring_rows, D_MODEL, device=device, dtype=ring_dtype)
+    ring.fill_synthetic(args.ring_rows, seed=42 + rank)  # every rank owns its own shard of rows
+    loader = RingLoader(ring, B, shuffle=True, seed=42)
+    total = args.warmup + 2 * args.steps + 8
+    trainer.setup_scheduler(max(total, 20000))
+
+    def batches():
+        while True:
+            for b in loader:
+                if len(b) == B:
+                    yield b
+
+    it = batches()
+    for _ in range(args.warmup):
+        trainer.train_step(next(it))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    eng = model._engine
+    prec = N.PREC_BF16 if args.precision == "bf16" else N.PREC_FP32
+    handle = eng.ctx(prec, B)
+    # events around the dominant kernel only (two event records per step) inside the timed region
+    dominant = N.lib().wsae_kernel_name  # noqa: F841
+    kid = -1 if args.profile_all else 6  # WSAE_K_WGRAD
+    N.check(N.lib().wsae_profile_enable(handle, kid, args.steps), "wsae_profile_enable")
+
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = trainer.train_step(next(it))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = N.profile_read(handle)
+    N.check(N.lib().wsae_profile_disable(handle), "wsae_profile_disable")
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        f_dense = 12 * D_MODEL * HIDDEN  # flop per activation, the reference's 2 fwd + 4 bwd dense GEMMs
+        # roofline of the dominant kernel: the two weight-gradient contractions, [H,B]x[B,D] each
+        n_w, ms_w = prof.get("wgrad", (0, 0.0))
+        roof = None
+        if n_w:
+            flops_per_launch = 2 * (2.0 * HIDDEN * D_MODEL * B)
+            achieved = flops_per_launch / (ms_w / n_w * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "wgrad_kernel<bf16>", "achieved": achieved,
+                    "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
+                    "traffic": None, "avg_launch_ms": ms_w / n_w, "launches": n_w,
+                    "step_dense_equiv_tflops": value * f_dense / 1e12,
+                    "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS}
+        out = {
+            "metric": "activations/sec through SAE train step (d=384->3072, k=32)",
+            "value": value, "unit": "activations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: TopKSAE 384->3072 k=32 train step, synthetic "
+                                   "activations resident in the HBM ring buffer" + ("" if world == 1 else
+                                   f" (configs[2]: DDP x{world}, RCCL grad all-reduce)"),
+                       "batch_per_gpu": B, "global_batch": world * B, "ring_rows_per_gpu": args.ring_rows,
+                       "lr": 1e-4, "clip": 1.0, "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "final_loss": last.loss if last is not None else None,
+        }
+        if args.profile_all:
+            out["kernel_ms_per_step"] = {k: v[1] / max(v[0], 1) for k, v in prof.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

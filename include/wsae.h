@@ -1,0 +1,243 @@
+/*
+ * wsae.h -- C ABI of libwsae_hip.so: the MI355X (gfx950 / CDNA4) SAE train-step kernels.
+ *
+ * This is the drop-in boundary underneath the reference's Python module API.  The reference
+ * (omarkhursheed/whisper-sae) has no FFI layer of its own: its hot path is an implicit ATen op
+ * sequence issued from src/whisper_sae/sae/model.py and src/whisper_sae/sae/training.py.  Each
+ * entry point below names the reference lines whose arithmetic it replaces; the ctypes binding a
+ * maintainer adds on the reference side is shown in INTEGRATION.md and lives, for this build, in
+ * whisper-sae_amd/whisper_sae/_native.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every data pointer is a caller-owned DEVICE pointer (e.g. torch.Tensor.data_ptr()); nothing
+ *     is retained past the call except what a wsae_ctx / wsae_ring handle allocates for itself.
+ *   - every launch goes to the caller's stream (hipStream_t passed as void*); no hidden
+ *     synchronisation, no allocation inside launch functions (graph-capturable).
+ *   - return value: 0 = ok, negative = error; wsae_last_error() gives the thread-local message.
+ *   - one ctx per device per process; a ctx is not thread-safe.
+ *
+ * Flat parameter layout ("pack"): all five parameter tensors of a TopKSAE live in ONE float32
+ * buffer of wsae_param_count(D,H) elements (gradients, Adam exp_avg and exp_avg_sq use the same
+ * layout in their own buffers), so the optimizer is one pass and the data-parallel exchange is one
+ * RCCL all-reduce:
+ *     [ W_e  : H*D ]  encoder.weight, row-major [H][D]            (model.py:63)
+ *     [ W_dT : H*D ]  decoder.weight TRANSPOSED, row-major [H][D] (model.py:64; row h = decoder
+ *                     column h, so decode gathers contiguous rows and the unit-norm constraint of
+ *                     model.py:91-96 is a per-row operation)
+ *     [ b_e  : H   ]  encoder.bias
+ *     [ b_d  : D   ]  decoder.bias
+ *     [ b_pre: D   ]  pre-encoder bias                            (model.py:67)
+ */
+#ifndef WSAE_H_
+#define WSAE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSAE_VERSION 1
+
+/* error codes */
+#define WSAE_OK 0
+#define WSAE_ERR_INVALID (-1) /* bad argument / unsupported shape */
+#define WSAE_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define WSAE_ERR_NOMEM (-3)
+
+/* arithmetic mode of the two contractions (encode GEMM, weight-gradient GEMMs) */
+#define WSAE_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate ("use_amp": training.py:73-75,179) */
+#define WSAE_PREC_FP32 1 /* fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's CPU fp32 semantics */
+
+/* element type of an activation buffer handed in */
+#define WSAE_DT_F32 0
+#define WSAE_DT_BF16 1
+
+typedef struct wsae_ctx wsae_ctx;
+typedef struct wsae_ring wsae_ring;
+
+typedef struct wsae_config {
+    int32_t input_dim;  /* D: multiple of 32, <= 2048 */
+    int32_t hidden_dim; /* H: multiple of 32 */
+    int32_t k;          /* TopK k: 1..128, <= H */
+    int32_t max_batch;  /* largest B any call will pass */
+    int32_t precision;  /* WSAE_PREC_* */
+    int32_t device;     /* HIP device ordinal */
+} wsae_config;
+
+/* device-side step record written by the kernels, fetched lazily by the host
+ * (replaces the five .item() syncs of training.py:207-213) */
+typedef struct wsae_stats {
+    float loss;        /* mean((recon-x)^2)                 model.py:145 */
+    float l0;          /* mean_b count(hidden>0)            model.py:148 */
+    float grad_norm;   /* global L2 norm before clipping    training.py:188 */
+    float clip_coef;   /* min(1, max_norm/(norm+1e-6)) */
+    float dead_ratio;  /* get_dead_feature_ratio()          model.py:192-195 */
+    int32_t dead_count;
+    int32_t topk_fallback_rows; /* rows that took the exact bisection path of the TopK kernel */
+    int32_t reserved;
+} wsae_stats;
+
+const char* wsae_last_error(void);
+int wsae_version(void);
+
+/* number of float32 elements of the flat pack, and element offsets of its five segments
+ * (order: W_e, W_dT, b_e, b_d, b_pre) */
+int64_t wsae_param_count(int32_t input_dim, int32_t hidden_dim);
+int wsae_param_offsets(int32_t input_dim, int32_t hidden_dim, int64_t offsets[5]);
+
+/* ctx: dims + mode + all workspace (bf16 weight shadows, TopK scratch, partial-sum slabs). */
+int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out);
+int wsae_ctx_destroy(wsae_ctx* ctx);
+size_t wsae_ctx_workspace_bytes(const wsae_ctx* ctx);
+
+/* Refresh what the kernels derive from the master weights: bf16 shadow of W_e and the folded
+ * encoder bias c[h] = b_e[h] - bf16(W_e)[h,:] . b_pre (BF16 mode).  Must be called after any
+ * change to `params` that did not go through wsae_adamw_step (which refreshes them itself). */
+int wsae_prepare(wsae_ctx* ctx, const float* params, void* stream);
+
+/* ---- forward --------------------------------------------------------------------------------
+ * x: [B, D] activations of dtype x_dtype; `rows` (nullable) gathers: batch row b is x[rows[b], :]
+ * (this is how batches are drawn from the on-device ring buffer without a copy). */
+
+/* TopKSAE.encode up to the TopK (model.py:108-114): pre = (x - b_pre) W_e^T + b_e, then the k
+ * largest per row, sorted descending (ties: lowest index first).  Compact code out:
+ * vals [B,k] f32 (pre-activation values, NOT yet relu'd), idx [B,k] i32.
+ * step_count (nullable, device int64): incremented by one = the dead-feature clock of
+ * model.py:175; pass it only for training-mode forwards. */
+int wsae_encode_topk(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                     const int32_t* rows, int32_t B, float* vals, int32_t* idx,
+                     int64_t* step_count, wsae_stats* stats, void* stream);
+
+/* Dense pre-activations [B,H] f32 (model.py:111), for API users / tests. */
+int wsae_encode_dense(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                      const int32_t* rows, int32_t B, float* pre, void* stream);
+
+/* hidden = zeros; hidden[idx] = relu(vals) (model.py:115-116).  hidden: [B,H] f32. */
+int wsae_densify(wsae_ctx* ctx, const float* vals, const int32_t* idx, int32_t B, float* hidden,
+                 void* stream);
+
+/* TopKSAE.decode for an arbitrary dense code (model.py:129): recon = hidden W_d^T + b_d + b_pre. */
+int wsae_decode_dense(wsae_ctx* ctx, const float* params, const float* hidden, int32_t B,
+                      float* recon, void* stream);
+
+/* Sparse decode + MSE + (optionally) the first half of backward, one pass over the compact code
+ * (model.py:129,145,148,168-181 and the autograd of them):
+ *   recon = sum_j relu(v_j) W_dT[idx_j,:] + b_d + b_pre ; loss = mean((recon-x)^2) ; l0
+ *   want_bwd: g = 2 (recon-x)/(B*D) kept in ctx workspace, dpre[b,j] = (v_j>0) ? g . W_dT[idx_j,:] : 0
+ *   last_activated (nullable, device int64[H]) with step_count (device int64): features with
+ *   v_j > 0 get last_activated = *step_count.
+ * recon (nullable): [B,D] f32.  dpre (required when want_bwd): [B,k] f32.
+ * stats->loss / stats->l0 are written (device). */
+int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                     const int32_t* rows, const float* vals, const int32_t* idx, int32_t B,
+                     float* recon, int32_t want_bwd, float* dpre, int64_t* last_activated,
+                     const int64_t* step_count, wsae_stats* stats, void* stream);
+
+/* Second half of backward (autograd of model.py:111,129 w.r.t. the parameters): the two
+ * [H,B]x[B,D] contractions on MFMA with the sparse operand rebuilt in LDS from the compact code,
+ * plus the three bias gradients.  Needs the g left in ctx by wsae_decode_loss(want_bwd=1) on the
+ * same batch.  grads: flat pack, overwritten. */
+int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                      const int32_t* rows, const float* vals, const int32_t* idx,
+                      const float* dpre, int32_t B, float* grads, void* stream);
+
+/* dL/dx (only the autograd API path needs it): dx = dpre W_e - g.  dx: [B,D] f32. */
+int wsae_input_grad(wsae_ctx* ctx, const float* params, const int32_t* idx, const float* dpre,
+                    int32_t B, float* dx, void* stream);
+
+/* ---- optimizer tail (training.py:186-198) -----------------------------------------------------
+ * global-L2 clip (clip_grad_norm_, max_norm <= 0 disables) -> AdamW (torch semantics, step is the
+ * 1-based update count) -> decoder column renorm (model.py:91-96, if normalize_decoder) ->
+ * refresh of the derived shadows.  grads are scaled by grad_scale first (1/world_size after a
+ * SUM all-reduce).  All four buffers use the flat pack layout. */
+int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads, float* exp_avg,
+                    float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int32_t step, float max_norm, float grad_scale,
+                    int32_t normalize_decoder, wsae_stats* stats, void* stream);
+
+/* F.normalize(decoder.weight, dim=0) alone (model.py:91-96) + shadow refresh. */
+int wsae_normalize_decoder(wsae_ctx* ctx, float* params, void* stream);
+
+/* ---- dead features (model.py:183-257) -------------------------------------------------------- */
+/* stats->dead_count / dead_ratio = #(step_count - last_activated > threshold); mask (nullable):
+ * uint8[H]. */
+int wsae_dead_scan(wsae_ctx* ctx, const int64_t* last_activated, const int64_t* step_count,
+                   int64_t threshold, uint8_t* mask, wsae_stats* stats, void* stream);
+
+/* resample_dead_features (model.py:197-257).  Call order mirrors the reference: (1) wsae_dead_scan
+ * -> dead_mask (model.py:215, BEFORE the forward); (2) the forward on `inputs` (encode_topk +
+ * decode_loss with a recon buffer; in train mode it bumps the dead-feature clock, model.py:229);
+ * (3) wsae_row_errors -> row_err [Br] = sum_d (x-recon)^2; (4) wsae_resample_dead: dead features
+ * ascending (at most num_cap, <0 = all), rows by error descending, the L2-normalised raw input row
+ * goes to W_e[f,:] and W_dT[f,:], b_e[f] = 0, last_activated[f] = *step_count.  Adam moments
+ * untouched.  n_dead_out (device int32): the capped dead count the reference returns
+ * (model.py:257), even when fewer than that many rows exist. */
+int wsae_row_errors(wsae_ctx* ctx, const void* x, int32_t x_dtype, const int32_t* rows,
+                    const float* recon, int32_t B, float* row_err, void* stream);
+int wsae_resample_dead(wsae_ctx* ctx, float* params, const void* inputs, int32_t x_dtype,
+                       const int32_t* rows, int32_t Br, const float* row_err,
+                       const uint8_t* dead_mask, int64_t* last_activated,
+                       const int64_t* step_count, int32_t num_cap, int32_t* n_dead_out,
+                       void* stream);
+
+/* ---- on-device activation ring buffer (replaces data/feature_cache.py:169-197) ---------------
+ * capacity rows of D elements (bf16 or f32) resident in HBM; producers push blocks of rows,
+ * the trainer draws batches as row-index lists (a seeded permutation per epoch), and the kernels
+ * gather rows straight from the ring. */
+int wsae_ring_create(int32_t device, int64_t capacity_rows, int32_t dim, int32_t dtype,
+                     wsae_ring** out);
+int wsae_ring_destroy(wsae_ring* ring);
+void* wsae_ring_data(wsae_ring* ring);         /* device pointer of row 0 */
+int64_t wsae_ring_size(const wsae_ring* ring); /* rows currently valid */
+/* append n_rows rows ([n_rows, D], device pointer, src_dtype f32/bf16 -> converted to the ring's
+ * dtype), wrapping around and overwriting the oldest rows once full */
+int wsae_ring_push(wsae_ring* ring, const void* src, int32_t src_dtype, int64_t n_rows, void* stream);
+/* rows_out[i] = perm_{seed,epoch}(offset + i) mod size, i < n: a bijective shuffle of [0,size)
+ * (the RandomSampler of feature_cache.py:191-197), computed on device */
+int wsae_ring_sample(wsae_ring* ring, uint64_t seed, int64_t epoch, int64_t offset, int32_t n,
+                     int32_t* rows_out, void* stream);
+/* fill with deterministic synthetic activations ~N(0,1) (bench / tests) */
+int wsae_ring_fill_synthetic(wsae_ring* ring, uint64_t seed, int64_t n_rows, void* stream);
+
+/* ---- in-library kernel timing (bench.py's roofline leg) ----------------------------------------
+ * When enabled for a kernel id, every launch of that kernel on this ctx is bracketed by a pair of
+ * HIP events recorded on the launch stream (up to max_samples launches, then recording stops).
+ * wsae_profile_read synchronises the recorded events and returns launch count and summed
+ * duration.  kernel_id -1 = all kernels.  Ids: see wsae_kernel_name(). */
+#define WSAE_K_STAGE_BATCH 0
+#define WSAE_K_ENCODE_GEMM 1
+#define WSAE_K_TOPK 2
+#define WSAE_K_DECODE 3
+#define WSAE_K_DECODE_FINALIZE 4
+#define WSAE_K_TRANSPOSE_G 5
+#define WSAE_K_WGRAD 6
+#define WSAE_K_BIAS_GRADS 7
+#define WSAE_K_SQNORM 8
+#define WSAE_K_ADAMW 9
+#define WSAE_K_ROWNORM 10
+#define WSAE_K_PREPARE 11
+#define WSAE_K_DEAD_SCAN 12
+#define WSAE_K_MEMSET 13
+#define WSAE_K_COUNT 14
+const char* wsae_kernel_name(int32_t kernel_id);
+int wsae_profile_enable(wsae_ctx* ctx, int32_t kernel_id, int32_t max_samples);
+int wsae_profile_disable(wsae_ctx* ctx);
+int wsae_profile_read(wsae_ctx* ctx, int32_t kernel_id, int32_t* n_launches, double* total_ms);
+
+/* ---- ReLU SAE (model.py:260-322), dense path ------------------------------------------------- */
+/* params pack for ReLUSAE: [W_e H*D | W_dT H*D | b_e H | b_d D] (no b_pre; pass the TopK pack with
+ * b_pre = 0 and relu=1).  hidden [B,H] f32 out; loss = mse + sparsity_weight * mean|hidden|. */
+int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                      const int32_t* rows, int32_t B, float sparsity_weight, float* hidden,
+                      float* recon, wsae_stats* stats, float* sparsity_loss_out, void* stream);
+int wsae_relu_backward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                       const int32_t* rows, int32_t B, float sparsity_weight, const float* hidden,
+                       const float* recon, float* grads, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSAE_H_ */

@@ -1,0 +1,144 @@
+// Shared device/host helpers for libwsae_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "wsae.h"
+
+// ------------------------------------------------------------------------------------------------
+// host side: error plumbing + ctx definition
+// ------------------------------------------------------------------------------------------------
+void wsae_set_error(const char* fmt, ...);
+
+#define WSAE_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            wsae_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                     \
+            return WSAE_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define WSAE_REQUIRE(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            wsae_set_error(__VA_ARGS__); \
+            return WSAE_ERR_INVALID;     \
+        }                                \
+    } while (0)
+
+#define WSAE_LAUNCH_CHECK()                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = hipGetLastError();                                                   \
+        if (e_ != hipSuccess) {                                                              \
+            wsae_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                        \
+            return WSAE_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// number of partial-sum slots every reduction in the library uses (one per producing block,
+// blocks beyond it fold round-robin): fixed so that the reduction order is deterministic.
+#define WSAE_MAX_PARTIALS 1024
+
+struct wsae_prof {
+    unsigned mask;                      // bit per kernel id
+    int max_samples;
+    int count[WSAE_K_COUNT];
+    hipEvent_t* ev[WSAE_K_COUNT];       // 2*max_samples events per enabled kernel
+};
+
+struct wsae_ctx {
+    wsae_prof prof;
+    int D, H, K, maxB, prec, device;
+    int64_t P;            // flat pack element count
+    int64_t off[5];       // W_e, W_dT, b_e, b_d, b_pre
+    // ---- derived shadows -------------------------------------------------------------------
+    bf16_t* We_bf16;      // [H][D]  (BF16 mode)
+    float* c_fold;        // [H] folded encoder bias (BF16 mode)
+    // ---- per-batch workspace ---------------------------------------------------------------
+    void* xb;             // [maxB][D] staged batch in compute dtype (bf16 | f32 = x - b_pre)
+    void* xT;             // [D][maxB] its transpose (B operand of the dW_e contraction)
+    void* gT;             // [D][maxB] g = 2(recon-x)/(BD) transposed, compute dtype
+    float* g;             // [maxB][D] fp32 g (dx path, db_d)
+    float* pre;           // [maxB][H] pre-activation scratch (TopK input)
+    float* part_loss;     // [WSAE_MAX_PARTIALS]
+    float* part_l0;       // [WSAE_MAX_PARTIALS]
+    float* part_dbd;      // [WSAE_MAX_PARTIALS][D]
+    float* part_sq;       // [WSAE_MAX_PARTIALS]
+    float* colnorm;       // [H] decoder column sum of squares scratch
+    int32_t* counters;    // small int scratch (fallback rows, dead count, resample cursors)
+    int32_t* dead_list;   // [H] compacted dead feature indices (resample)
+    int32_t* row_order;   // [maxB] rows sorted by error (resample)
+    int n_dec_blocks;     // blocks used by the last decode launch (partials to reduce)
+    size_t ws_bytes;
+};
+
+// bracket one kernel launch with events when profiling is enabled for its id
+#define WSAE_PROF_BEGIN(ctx, id, st)                                                          \
+    const bool prof_on_##id = ((ctx)->prof.mask >> (id)) & 1u &&                               \
+                              (ctx)->prof.count[id] < (ctx)->prof.max_samples;                 \
+    if (prof_on_##id) (void)hipEventRecord((ctx)->prof.ev[id][2 * (ctx)->prof.count[id]], st)
+#define WSAE_PROF_END(ctx, id, st)                                                            \
+    if (prof_on_##id) {                                                                       \
+        (void)hipEventRecord((ctx)->prof.ev[id][2 * (ctx)->prof.count[id] + 1], st);           \
+        (ctx)->prof.count[id]++;                                                              \
+    }
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+#define WSAE_WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// deterministic block reduction of one float per thread (blockDim.x multiple of 64, <= 1024);
+// result valid in thread 0.  `scratch` must hold blockDim.x/64 floats.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+
+// load one activation element as float
+template <int DT>
+__device__ __forceinline__ float load_act(const void* p, int64_t i) {
+    if (DT == WSAE_DT_BF16) return (float)((const bf16_t*)p)[i];
+    return ((const float*)p)[i];
+}
+
+#endif  // __HIPCC__

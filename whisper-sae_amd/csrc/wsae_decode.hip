@@ -1,0 +1,265 @@
+// Sparse decode + MSE residual + first half of backward, from the compact TopK code.
+//   reference: TopKSAE.decode / forward / _update_dead_features, model.py:120-181, and the
+//   autograd of them: g = 2(recon-x)/(BD), dh = g W_d, dpre = dh * 1[v>0].
+//
+// One wave per batch row.  A row of W_dT (one decoder column) is D contiguous floats, so the
+// k gathers per row are coalesced; lane l owns elements l, l+64, ... of the row.
+#include "wsae_common.h"
+
+template <int EPL, int XDT, bool BWD, bool ROUND_DPRE>
+__global__ void __launch_bounds__(256)
+decode_kernel(const float* __restrict__ WdT, const float* __restrict__ bd, const float* __restrict__ bpre,
+              const void* __restrict__ x, const int32_t* __restrict__ rows, const float* __restrict__ vals,
+              const int32_t* __restrict__ idx, int B, int D, int K, float* __restrict__ recon_out,
+              float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated,
+              const int64_t* __restrict__ step_count, float* __restrict__ part_loss, float* __restrict__ part_l0,
+              float* __restrict__ part_dbd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)smem;          // [8] block reduction scratch
+    float* dbd_s = (float*)smem + 8;    // [4][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float scale = 2.0f / ((float)B * (float)D);
+    const int64_t step = (last_activated && step_count) ? *step_count : 0;
+
+    float bsum[EPL], dbd[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int d = lane + 64 * e;
+        bsum[e] = d < D ? bd[d] + bpre[d] : 0.f;
+        dbd[e] = 0.f;
+    }
+    float loss_acc = 0.f;
+    int l0_acc = 0;
+
+    for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+        float rec[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) rec[e] = bsum[e];
+        const int64_t code = (int64_t)b * K;
+        // ---- decode: recon = sum_j relu(v_j) * W_dT[idx_j, :] ----
+        for (int jb = 0; jb < K; jb += 64) {
+            const int nj = min(64, K - jb);
+            const float v = (lane < nj) ? vals[code + jb + lane] : 0.f;
+            const int f = (lane < nj) ? idx[code + jb + lane] : 0;
+            const bool on = v > 0.f;
+            l0_acc += __popcll(__ballot(on));
+            if (on && last_activated) last_activated[f] = step;  // model.py:178-181 (same value from every writer)
+            for (int j = 0; j < nj; ++j) {
+                const float vj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j));
+                if (!(vj > 0.f)) continue;
+                const int fj = __builtin_amdgcn_readlane(f, j);
+                const float* w = WdT + (int64_t)fj * D;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int d = lane + 64 * e;
+                    if (d < D) rec[e] = fmaf(vj, w[d], rec[e]);
+                }
+            }
+        }
+        // ---- residual, loss, g ----
+        const int64_t src = rows ? (int64_t)rows[b] : (int64_t)b;
+        float g[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int d = lane + 64 * e;
+            g[e] = 0.f;
+            if (d < D) {
+                const float xv = load_act<XDT>(x, src * D + d);
+                const float r = rec[e] - xv;
+                loss_acc = fmaf(r, r, loss_acc);
+                g[e] = r * scale;
+                dbd[e] += g[e];
+                if (recon_out) recon_out[(int64_t)b * D + d] = rec[e];
+                if (BWD) g_out[(int64_t)b * D + d] = g[e];
+            }
+        }
+        // ---- dpre_j = (v_j > 0) ? g . W_dT[idx_j, :] : 0 ----
+        if (BWD) {
+            for (int jb = 0; jb < K; jb += 64) {
+                const int nj = min(64, K - jb);
+                const float v = (lane < nj) ? vals[code + jb + lane] : 0.f;
+                const int f = (lane < nj) ? idx[code + jb + lane] : 0;
+                float mine = 0.f;
+                for (int j = 0; j < nj; ++j) {
+                    const float vj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j));
+                    if (!(vj > 0.f)) continue;
+                    const int fj = __builtin_amdgcn_readlane(f, j);
+                    const float* w = WdT + (int64_t)fj * D;
+                    float dot = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const int d = lane + 64 * e;
+                        if (d < D) dot = fmaf(g[e], w[d], dot);
+                    }
+                    dot = wave_sum(dot);
+                    if (lane == j) mine = dot;
+                }
+                if (ROUND_DPRE) mine = (float)(bf16_t)mine;  // what the MFMA contraction will be fed
+                if (lane < nj) dpre[code + jb + lane] = mine;
+            }
+        }
+    }
+
+    // ---- block partials: loss / l0 reduced in fixed order by decode_finalize ----
+    const float bl = block_sum(loss_acc, red);
+    if (threadIdx.x == 0) part_loss[blockIdx.x] = bl;
+    const float b0 = block_sum(lane == 0 ? (float)l0_acc : 0.f, red);
+    if (threadIdx.x == 0) part_l0[blockIdx.x] = b0;
+    if (BWD) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int d = lane + 64 * e;
+            if (d < D) dbd_s[wave * D + d] = dbd[e];
+        }
+        __syncthreads();
+        // sum_b g joins the [D] accumulator at the head of part_dbd (zeroed by the launcher)
+        for (int d = threadIdx.x; d < D; d += 256)
+            atomicAdd(part_dbd + d, dbd_s[d] + dbd_s[D + d] + dbd_s[2 * D + d] + dbd_s[3 * D + d]);
+    }
+}
+
+__global__ void __launch_bounds__(256) decode_finalize_kernel(const float* __restrict__ part_loss,
+                                                              const float* __restrict__ part_l0, int n, int B, int D,
+                                                              wsae_stats* __restrict__ stats) {
+    __shared__ float red[8];
+    float a = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        a += part_loss[i];
+        c += part_l0[i];
+    }
+    const float ta = block_sum(a, red);
+    const float tc = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        stats->loss = ta / ((float)B * (float)D);
+        stats->l0 = tc / (float)B;
+    }
+}
+
+// g [B][D] f32 -> gT [D][ldT] in the contraction dtype, zero-padded beyond column B.
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_g_kernel(const float* __restrict__ g, T* __restrict__ gT, int B, int D,
+                                                          int ldT) {
+    __shared__ float tile[64][65];
+    const int b0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int b = b0 + r, d = d0 + tx;
+        tile[r][tx] = (b < B && d < D) ? g[(int64_t)b * D + d] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int d = d0 + r, b = b0 + tx;
+        if (d < D && b < ldT) gT[(int64_t)d * ldT + b] = (T)tile[tx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int EPL, int XDT>
+static void launch_decode(wsae_ctx* c, const float* params, const void* x, const int32_t* rows, const float* vals,
+                          const int32_t* idx, int B, float* recon, int want_bwd, float* dpre, int64_t* last_activated,
+                          const int64_t* step_count, int nblk, hipStream_t st) {
+    const float* WdT = params + c->off[1];
+    const float* bd = params + c->off[3];
+    const float* bpre = params + c->off[4];
+    const size_t sh = (8 + 4 * (size_t)c->D) * sizeof(float);
+#define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->D, c->K, recon, dpre, c->g, last_activated, step_count, \
+                 c->part_loss, c->part_l0, c->part_dbd
+    if (!want_bwd)
+        decode_kernel<EPL, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
+    else if (c->prec == WSAE_PREC_BF16)
+        decode_kernel<EPL, XDT, true, true><<<nblk, 256, sh, st>>>(DEC_ARGS);
+    else
+        decode_kernel<EPL, XDT, true, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
+#undef DEC_ARGS
+}
+
+template <int XDT>
+static int dispatch_decode(wsae_ctx* c, const float* params, const void* x, const int32_t* rows, const float* vals,
+                           const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
+                           int64_t* last_activated, const int64_t* step_count, int nblk, hipStream_t st) {
+    const int epl = ceil_div(c->D, 64);
+#define DEC_CASE(N)                                                                                              \
+    if (epl <= N) {                                                                                              \
+        launch_decode<N, XDT>(c, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated, step_count, \
+                              nblk, st);                                                                         \
+        return WSAE_OK;                                                                                          \
+    }
+    DEC_CASE(1) DEC_CASE(2) DEC_CASE(4) DEC_CASE(6) DEC_CASE(8) DEC_CASE(12) DEC_CASE(16) DEC_CASE(20) DEC_CASE(32)
+#undef DEC_CASE
+    wsae_set_error("decode: input_dim %d too large", c->D);
+    return WSAE_ERR_INVALID;
+}
+
+extern "C" int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                                const int32_t* rows, const float* vals, const int32_t* idx, int32_t B, float* recon,
+                                int32_t want_bwd, float* dpre, int64_t* last_activated, const int64_t* step_count,
+                                wsae_stats* stats, void* stream) {
+    WSAE_REQUIRE(ctx && params && x && vals && idx && stats, "wsae_decode_loss: null argument");
+    WSAE_REQUIRE(B >= 1 && B <= ctx->maxB, "wsae_decode_loss: batch %d outside [1, %d]", B, ctx->maxB);
+    WSAE_REQUIRE(!want_bwd || dpre, "wsae_decode_loss: want_bwd needs a dpre buffer");
+    WSAE_REQUIRE(!last_activated || step_count, "wsae_decode_loss: last_activated needs step_count");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = min(ceil_div(B, 4), WSAE_MAX_PARTIALS);
+    if (want_bwd) WSAE_HIP_CHECK(hipMemsetAsync(ctx->part_dbd, 0, (size_t)ctx->D * 4, st));
+    int rc;
+    WSAE_PROF_BEGIN(ctx, WSAE_K_DECODE, st);
+    if (x_dtype == WSAE_DT_F32)
+        rc = dispatch_decode<WSAE_DT_F32>(ctx, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,
+                                          step_count, nblk, st);
+    else if (x_dtype == WSAE_DT_BF16)
+        rc = dispatch_decode<WSAE_DT_BF16>(ctx, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,
+                                           step_count, nblk, st);
+    else {
+        wsae_set_error("wsae_decode_loss: unknown activation dtype %d", x_dtype);
+        return WSAE_ERR_INVALID;
+    }
+    if (rc) return rc;
+    WSAE_PROF_END(ctx, WSAE_K_DECODE, st);
+    WSAE_LAUNCH_CHECK();
+    ctx->n_dec_blocks = nblk;
+    WSAE_PROF_BEGIN(ctx, WSAE_K_DECODE_FINALIZE, st);
+    decode_finalize_kernel<<<1, 256, 0, st>>>(ctx->part_loss, ctx->part_l0, nblk, B, ctx->D, stats);
+    WSAE_PROF_END(ctx, WSAE_K_DECODE_FINALIZE, st);
+    WSAE_LAUNCH_CHECK();
+    if (want_bwd) {
+        const int ldT = (B + 127) / 128 * 128;
+        dim3 tg(ceil_div(ldT, 64), ceil_div(ctx->D, 64));
+        WSAE_PROF_BEGIN(ctx, WSAE_K_TRANSPOSE_G, st);
+        if (ctx->prec == WSAE_PREC_BF16)
+            transpose_g_kernel<bf16_t><<<tg, 256, 0, st>>>(ctx->g, (bf16_t*)ctx->gT, B, ctx->D, ldT);
+        else
+            transpose_g_kernel<float><<<tg, 256, 0, st>>>(ctx->g, (float*)ctx->gT, B, ctx->D, ldT);
+        WSAE_PROF_END(ctx, WSAE_K_TRANSPOSE_G, st);
+        WSAE_LAUNCH_CHECK();
+    }
+    return WSAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dL/dx = dpre W_e - g      (autograd API path only; model.py:108,145)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) input_grad_kernel(const float* __restrict__ We, const float* __restrict__ g,
+                                                         const int32_t* __restrict__ idx, const float* __restrict__ dpre,
+                                                         int B, int D, int K, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    for (int d = lane; d < D; d += 64) {
+        float a = -g[(int64_t)b * D + d];
+        for (int j = 0; j < K; ++j) {
+            const float dp = dpre[(int64_t)b * K + j];
+            if (dp != 0.f) a = fmaf(dp, We[(int64_t)idx[(int64_t)b * K + j] * D + d], a);
+        }
+        dx[(int64_t)b * D + d] = a;
+    }
+}
+
+extern "C" int wsae_input_grad(wsae_ctx* ctx, const float* params, const int32_t* idx, const float* dpre, int32_t B,
+                               float* dx, void* stream) {
+    WSAE_REQUIRE(ctx && params && idx && dpre && dx && B >= 1 && B <= ctx->maxB, "wsae_input_grad: bad argument");
+    input_grad_kernel<<<ceil_div(B, 4), 256, 0, (hipStream_t)stream>>>(params + ctx->off[0], ctx->g, idx, dpre, B, ctx->D,
+                                                                       ctx->K, dx);
+    WSAE_LAUNCH_CHECK();
+    return WSAE_OK;
+}

@@ -1,0 +1,345 @@
+// Encode path: batch staging, pre-activation GEMM on MFMA, per-row TopK with wavefront reductions.
+//   reference: TopKSAE.encode, src/whisper_sae/sae/model.py:98-118
+#include "wsae_common.h"
+#include "wsae_mfma.h"
+
+// ------------------------------------------------------------------------------------------------
+// stage_batch: gather + convert the batch once.
+//   xb [B][D]      compute dtype: bf16(x) (BF16 mode) or x - b_pre in f32 (FP32 mode, model.py:108)
+//   xT [D][ldT]    its transpose (Bt operand of the dW_e contraction), zero beyond column B
+// 64 x 64 tiles through LDS so both the read (along d) and the write (along b) are coalesced.
+// ------------------------------------------------------------------------------------------------
+template <int XDT, typename T>
+__global__ void __launch_bounds__(256) stage_batch_kernel(const void* __restrict__ x, const int32_t* __restrict__ rows,
+                                                          const float* __restrict__ bpre, T* __restrict__ xb,
+                                                          T* __restrict__ xT, int B, int D, int ldT) {
+    __shared__ float tile[64][65];
+    const int b0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty 0..3
+    for (int r = ty; r < 64; r += 4) {
+        const int b = b0 + r, d = d0 + tx;
+        float v = 0.f;
+        if (b < B && d < D) {
+            const int64_t src = rows ? (int64_t)rows[b] : (int64_t)b;
+            v = load_act<XDT>(x, src * D + d);
+            if (sizeof(T) == 4) v -= bpre[d];
+            xb[(int64_t)b * D + d] = (T)v;
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int d = d0 + r, b = b0 + tx;
+        if (d < D && b < ldT) xT[(int64_t)d * ldT + b] = (T)tile[tx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pre[b][h] = sum_d xb[b][d] * W[h][d] + bias[h]          (model.py:111)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) encode_gemm_kernel(const T* __restrict__ xb, const T* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ pre,
+                                                          int B, int H, int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + TILE_LDS_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * TILE_M, n0 = blockIdx.x * TILE_N;
+    constexpr int KT = Mfma<T>::KT;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    SlabRegs<T> ra, rb;
+    slab_load<T>(ra, xb, D, m0, B, 0, D, tid);
+    slab_load<T>(rb, W, D, n0, H, 0, D, tid);
+    const int nk = (D + KT - 1) / KT;
+    for (int kt = 0; kt < nk; ++kt) {
+        slab_store<T>(ra, As, tid);
+        slab_store<T>(rb, Bs, tid);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            slab_load<T>(ra, xb, D, m0, B, (kt + 1) * KT, D, tid);
+            slab_load<T>(rb, W, D, n0, H, (kt + 1) * KT, D, tid);
+        }
+        Mfma<T>::slab(As, Bs, wm * 64, wn * 64, lane, acc);
+        __syncthreads();
+    }
+    const int col = lane & 31, rq = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int h = n0 + wn * 64 + ni * 32 + col;
+            if (h >= H) continue;
+            const float bv = bias[h];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                if (b < B) pre[(int64_t)b * H + h] = acc[mi][ni][r] + bv;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TopK: one wave per row.
+//   key = (orderable(value) << 32) | ~index : descending key order == (value desc, index asc).
+//   1. per-lane maximum over the lane's share of the row;
+//   2. T = K-th largest of the 64 lane maxima (64 distinct elements >= T, so at least K elements of
+//      the row are >= T: a safe threshold, tight to roughly the 1.4*K-th largest);
+//   3. compact the elements with value >= T (ballot + mbcnt prefix) into an LDS list;
+//   4. bitonic sort of the list across the wave (1, 2 or 4 keys per lane), emit the first K.
+//   Rows with more than 256 candidates (heavy ties, adversarial layouts) or K > 64 take the exact
+//   path: bisection on the 64-bit key for the K-th largest key, then the same compaction + sort.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_f32(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, m, 64);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int NPL>
+__device__ __forceinline__ void wave_sort_desc(uint64_t (&key)[NPL], int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64 * NPL; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= NPL) {
+                const int lm = stride / NPL;
+#pragma unroll
+                for (int i = 0; i < NPL; ++i) {
+                    const uint64_t other = shfl_xor_u64(key[i], lm);
+                    const int p = lane * NPL + i;
+                    const bool desc = (p & size) == 0;
+                    const bool lower = (p & stride) == 0;
+                    const bool keep_max = (lower == desc);
+                    const uint64_t mx = key[i] > other ? key[i] : other;
+                    const uint64_t mn = key[i] > other ? other : key[i];
+                    key[i] = keep_max ? mx : mn;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPL; ++i) {
+                    if ((i & stride) == 0) {
+                        const int j = i | stride;
+                        const int p = lane * NPL + i;
+                        const bool desc = (p & size) == 0;
+                        const uint64_t a = key[i], b = key[j];
+                        const uint64_t mx = a > b ? a : b, mn = a > b ? b : a;
+                        key[i] = desc ? mx : mn;
+                        key[j] = desc ? mn : mx;
+                    }
+                }
+            }
+        }
+    }
+}
+
+#define TOPK_CAP 256
+
+template <int NPL>
+__device__ __forceinline__ void topk_emit(const uint64_t* list, int count, int K, int lane, float* vrow, int32_t* irow) {
+    uint64_t key[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int p = lane * NPL + i;
+        key[i] = p < count ? list[p] : 0ull;
+    }
+    wave_sort_desc<NPL>(key, lane);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int p = lane * NPL + i;
+        if (p < K) {
+            vrow[p] = ord_f32((uint32_t)(key[i] >> 32));
+            irow[p] = (int32_t)(~(uint32_t)key[i]);
+        }
+    }
+}
+
+// compact every element with key >= kmin into list (wave-private LDS); returns the count
+// (wave-uniform).  Stops storing beyond TOPK_CAP but keeps counting.
+__device__ __forceinline__ int topk_compact(const float* __restrict__ row, int H, uint64_t kmin, uint64_t* list,
+                                            int lane) {
+    int base = 0;
+    for (int e0 = 0; e0 < H; e0 += 256) {
+        const int e = e0 + lane * 4;
+        float4 v = make_float4(0, 0, 0, 0);
+        const bool in = e < H;
+        if (in) v = *(const float4*)(row + e);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint64_t key = ((uint64_t)f32_ord(vv[c]) << 32) | (uint32_t)(~(uint32_t)(e + c));
+            const bool pass = in && key >= kmin;
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (pass && pos < TOPK_CAP) list[pos] = key;
+                base += __popcll(m);
+            }
+        }
+    }
+    return base;
+}
+
+__device__ __forceinline__ int topk_count_ge(const float* __restrict__ row, int H, uint64_t kmin, int lane) {
+    int cnt = 0;
+    for (int e0 = 0; e0 < H; e0 += 256) {
+        const int e = e0 + lane * 4;
+        if (e < H) {
+            const float4 v = *(const float4*)(row + e);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint64_t key = ((uint64_t)f32_ord(vv[c]) << 32) | (uint32_t)(~(uint32_t)(e + c));
+                cnt += key >= kmin ? 1 : 0;
+            }
+        }
+    }
+    return wave_sum_i(cnt);
+}
+
+__global__ void __launch_bounds__(256) topk_kernel(const float* __restrict__ pre, int B, int H, int K,
+                                                   float* __restrict__ vals, int32_t* __restrict__ idx,
+                                                   int64_t* __restrict__ step_count, int32_t* __restrict__ fallback_rows) {
+    __shared__ uint64_t lists[4][TOPK_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && step_count) *step_count += 1;  // model.py:175
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const float* row = pre + (int64_t)b * H;
+    uint64_t* list = lists[wave];
+
+    uint64_t kmin = 0;
+    if (K <= 64) {
+        float m = -INFINITY;
+        bool any = false;
+        for (int e = lane * 4; e < H; e += 256) {
+            const float4 v = *(const float4*)(row + e);
+            m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            any = true;
+        }
+        uint64_t mk[1] = {any ? ((uint64_t)f32_ord(m) << 32) : 0ull};
+        wave_sort_desc<1>(mk, lane);
+        // K-th largest lane maximum; lanes without elements carry key 0 (below every value)
+        const uint32_t thi = __shfl((uint32_t)(mk[0] >> 32), K - 1, 64);
+        kmin = (uint64_t)thi << 32;  // value >= T, any index
+    }
+    int count = topk_compact(row, H, kmin, list, lane);
+    if (count > TOPK_CAP || count < K) {
+        // exact path: the K-th largest 64-bit key by bisection from the top bit down
+        if (lane == 0) atomicAdd(fallback_rows, 1);
+        uint64_t prefix = 0;
+        for (int bit = 63; bit >= 0; --bit) {
+            const uint64_t cand = prefix | (1ull << bit);
+            if (topk_count_ge(row, H, cand, lane) >= K) prefix = cand;
+        }
+        count = topk_compact(row, H, prefix, list, lane);  // == K exactly (keys are distinct)
+    }
+    float* vrow = vals + (int64_t)b * K;
+    int32_t* irow = idx + (int64_t)b * K;
+    if (count <= 64)
+        topk_emit<1>(list, count, K, lane, vrow, irow);
+    else if (count <= 128)
+        topk_emit<2>(list, count, K, lane, vrow, irow);
+    else
+        topk_emit<4>(list, count, K, lane, vrow, irow);
+}
+
+// hidden = zeros; hidden[b][idx] = relu(val)        (model.py:115-116)
+__global__ void __launch_bounds__(256) densify_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx,
+                                                      int B, int H, int K, float* __restrict__ hidden) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * K) return;
+    const int b = (int)(i / K);
+    const float v = vals[i];
+    hidden[(int64_t)b * H + idx[i]] = v > 0.f ? v : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+template <typename T>
+static int stage_and_gemm(wsae_ctx* c, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,
+                          float* pre, hipStream_t st) {
+    const int D = c->D, H = c->H;
+    const int ldT = round_up(B, 128);
+    dim3 sg(ceil_div(ldT, 64), ceil_div(D, 64));
+    WSAE_PROF_BEGIN(c, WSAE_K_STAGE_BATCH, st);
+    if (x_dtype == WSAE_DT_F32)
+        stage_batch_kernel<WSAE_DT_F32, T><<<sg, 256, 0, st>>>(x, rows, params + c->off[4], (T*)c->xb, (T*)c->xT, B, D, ldT);
+    else
+        stage_batch_kernel<WSAE_DT_BF16, T><<<sg, 256, 0, st>>>(x, rows, params + c->off[4], (T*)c->xb, (T*)c->xT, B, D, ldT);
+    WSAE_PROF_END(c, WSAE_K_STAGE_BATCH, st);
+    WSAE_LAUNCH_CHECK();
+    const T* W = sizeof(T) == 2 ? (const T*)c->We_bf16 : (const T*)(params + c->off[0]);
+    const float* bias = sizeof(T) == 2 ? c->c_fold : params + c->off[2];
+    dim3 gg(ceil_div(H, TILE_N), ceil_div(B, TILE_M));
+    WSAE_PROF_BEGIN(c, WSAE_K_ENCODE_GEMM, st);
+    encode_gemm_kernel<T><<<gg, 256, 2 * TILE_LDS_BYTES, st>>>((const T*)c->xb, W, bias, pre, B, H, D);
+    WSAE_PROF_END(c, WSAE_K_ENCODE_GEMM, st);
+    WSAE_LAUNCH_CHECK();
+    return WSAE_OK;
+}
+
+static int check_batch(const wsae_ctx* c, const void* x, int x_dtype, int B, const char* who) {
+    WSAE_REQUIRE(c && x, "%s: null argument", who);
+    WSAE_REQUIRE(B >= 1 && B <= c->maxB, "%s: batch %d outside [1, max_batch=%d]", who, B, c->maxB);
+    WSAE_REQUIRE(x_dtype == WSAE_DT_F32 || x_dtype == WSAE_DT_BF16, "%s: unknown activation dtype %d", who, x_dtype);
+    return WSAE_OK;
+}
+
+extern "C" int wsae_encode_dense(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                                 const int32_t* rows, int32_t B, float* pre, void* stream) {
+    int rc = check_batch(ctx, x, x_dtype, B, "wsae_encode_dense");
+    if (rc) return rc;
+    WSAE_REQUIRE(params && pre, "wsae_encode_dense: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    return ctx->prec == WSAE_PREC_BF16 ? stage_and_gemm<bf16_t>(ctx, params, x, x_dtype, rows, B, pre, st)
+                                       : stage_and_gemm<float>(ctx, params, x, x_dtype, rows, B, pre, st);
+}
+
+extern "C" int wsae_encode_topk(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                                const int32_t* rows, int32_t B, float* vals, int32_t* idx, int64_t* step_count,
+                                wsae_stats* stats, void* stream) {
+    int rc = check_batch(ctx, x, x_dtype, B, "wsae_encode_topk");
+    if (rc) return rc;
+    WSAE_REQUIRE(params && vals && idx, "wsae_encode_topk: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    rc = ctx->prec == WSAE_PREC_BF16 ? stage_and_gemm<bf16_t>(ctx, params, x, x_dtype, rows, B, ctx->pre, st)
+                                     : stage_and_gemm<float>(ctx, params, x, x_dtype, rows, B, ctx->pre, st);
+    if (rc) return rc;
+    int32_t* fb = stats ? &stats->topk_fallback_rows : ctx->counters;
+    WSAE_PROF_BEGIN(ctx, WSAE_K_TOPK, st);
+    topk_kernel<<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb);
+    WSAE_PROF_END(ctx, WSAE_K_TOPK, st);
+    WSAE_LAUNCH_CHECK();
+    return WSAE_OK;
+}
+
+extern "C" int wsae_densify(wsae_ctx* ctx, const float* vals, const int32_t* idx, int32_t B, float* hidden,
+                            void* stream) {
+    WSAE_REQUIRE(ctx && vals && idx && hidden && B >= 1, "wsae_densify: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    WSAE_HIP_CHECK(hipMemsetAsync(hidden, 0, (size_t)B * ctx->H * 4, st));
+    const int64_t n = (int64_t)B * ctx->K;
+    densify_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(vals, idx, B, ctx->H, ctx->K, hidden);
+    WSAE_LAUNCH_CHECK();
+    return WSAE_OK;
+}

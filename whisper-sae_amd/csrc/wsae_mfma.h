@@ -1,0 +1,104 @@
+// MFMA tile machinery shared by the encode GEMM and the weight-gradient GEMMs.
+//
+// Both contractions are "NT": C[m][n] = sum_k A[m][k] * Bt[n][k], with K contiguous in both
+// operands, so every MFMA fragment is one contiguous LDS read.  Workgroup tile 128 x 128, four
+// waves in a 2 x 2 arrangement, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator
+// VGPRs).  K is walked in slabs of 128 bytes per row (64 bf16 or 32 f32); LDS rows are padded to
+// 144 bytes, which makes the 16-byte fragment reads of any 16 consecutive rows hit 16 distinct
+// 4-bank slots (bank = (addr/4) % 64, rows 36 dwords apart: cdna guide, LDS section).
+//
+// Fragment maps (gfx950, cdna guide section 3):
+//   v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k = 8*(l>>5)+j], B[k = 8*(l>>5)+j][col l&31]
+//   v_mfma_f32_32x32x2_f32  : lane l holds A[row l&31][k = l>>5],        B[k = l>>5][col l&31]
+//   C/D (both)              : reg r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]
+#pragma once
+
+#include "wsae_common.h"
+
+#define TILE_M 128
+#define TILE_N 128
+#define LDS_ROW_BYTES 144  // 128 data + 16 pad
+#define TILE_LDS_BYTES (128 * LDS_ROW_BYTES)
+
+template <typename T>
+struct Mfma;
+
+template <>
+struct Mfma<bf16_t> {
+    static constexpr int KT = 64;  // elements per K slab
+    // acc[mi][ni] += A(64 rows at a_row0) x Bt(64 rows at b_row0) over the whole slab
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
+                                                f32x16 (&acc)[2][2]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *(const bf16x8*)(As + (a_row0 + i * 32 + r) * LDS_ROW_BYTES + kk * 32 + h * 16);
+                b[i] = *(const bf16x8*)(Bs + (b_row0 + i * 32 + r) * LDS_ROW_BYTES + kk * 32 + h * 16);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+
+template <>
+struct Mfma<float> {
+    static constexpr int KT = 32;
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
+                                                f32x16 (&acc)[2][2]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *(const float*)(As + (a_row0 + i * 32 + r) * LDS_ROW_BYTES + (kk * 2 + h) * 4);
+                b[i] = *(const float*)(Bs + (b_row0 + i * 32 + r) * LDS_ROW_BYTES + (kk * 2 + h) * 4);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+
+// Dense operand slab: rows [row0, row0+128) x K elements [k0, k0+KT) of a row-major matrix with
+// leading dimension ld (elements).  Rows >= n_rows and K chunks >= k_total read as zero.
+// 1024 16-byte chunks per slab, 4 per thread; 8 consecutive threads cover one 128-byte row.
+template <typename T>
+struct SlabRegs {
+    uint4 v[4];
+};
+
+template <typename T>
+__device__ __forceinline__ void slab_load(SlabRegs<T>& r, const T* __restrict__ base, int64_t ld, int row0,
+                                          int n_rows, int k0, int k_total, int tid) {
+    constexpr int EPC = 16 / (int)sizeof(T);  // elements per chunk
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        const int row = row0 + (c >> 3);
+        const int k = k0 + (c & 7) * EPC;
+        if (row < n_rows && k < k_total)
+            r.v[i] = *(const uint4*)(base + (int64_t)row * ld + k);
+        else
+            r.v[i] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void slab_store(const SlabRegs<T>& r, char* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        *(uint4*)(lds + (c >> 3) * LDS_ROW_BYTES + (c & 7) * 16) = r.v[i];
+    }
+}

@@ -1,0 +1,321 @@
+// Optimizer tail and weight maintenance.
+//   reference: training.py:186-198 (clip_grad_norm_ -> AdamW.step -> normalize_decoder_weights),
+//              model.py:91-96 (F.normalize(decoder.weight, dim=0)), model.py:183-257 (dead features)
+#include "wsae_common.h"
+
+int wsae_prepare_launch(wsae_ctx* ctx, const float* params, hipStream_t st);  // wsae_ctx.hip
+
+// ---- global gradient norm: per-block partial sums of (scale*g)^2, fixed reduction order ----------
+__global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g, int64_t n4, float scale,
+                                                     float* __restrict__ part) {
+    __shared__ float red[8];
+    float a = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = ((const float4*)g)[i];
+        const float x = v.x * scale, y = v.y * scale, z = v.z * scale, w = v.w * scale;
+        a += x * x + y * y + z * z + w * w;
+    }
+    const float t = block_sum(a, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// ---- clip + AdamW, one float4 per thread per iteration ------------------------------------------
+// torch.optim.AdamW (single step t): p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g g;
+// denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom.   g is first scaled by
+// grad_scale (1/world after a SUM all-reduce) and by the clip coefficient
+// min(1, max_norm/(||g||+1e-6)) (torch.nn.utils.clip_grad_norm_).
+__global__ void __launch_bounds__(256)
+adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+             int64_t n4, const float* __restrict__ part_sq, int nparts, float max_norm, float grad_scale, float lr_wd,
+             float beta1, float beta2, float eps, float step_size, float bc2_sqrt, wsae_stats* __restrict__ stats) {
+    __shared__ float red[8];
+    __shared__ float coef_s;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += part_sq[i];
+    const float tot = block_sum(a, red);
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(tot);
+        float coef = 1.f;
+        if (max_norm > 0.f) coef = fminf(1.f, max_norm / (nrm + 1e-6f));
+        coef_s = coef * grad_scale;
+        if (blockIdx.x == 0 && stats) {
+            stats->grad_norm = nrm;
+            stats->clip_coef = coef;
+        }
+    }
+    __syncthreads();
+    const float gs = coef_s;
+    const float decay = 1.f - lr_wd;
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+        const float4 gg = ((const float4*)g)[i];
+        float* pa = (float*)&pp; float* ma = (float*)&mm; float* va = (float*)&vv;
+        const float* ga = (const float*)&gg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gc = ga[c] * gs;
+            const float mn = ma[c] + (gc - ma[c]) * omb1;
+            const float vn = beta2 * va[c] + omb2 * gc * gc;
+            const float denom = sqrtf(vn) / bc2_sqrt + eps;
+            pa[c] = pa[c] * decay - step_size * (mn / denom);
+            ma[c] = mn;
+            va[c] = vn;
+        }
+        ((float4*)p)[i] = pp;
+        ((float4*)m)[i] = mm;
+        ((float4*)v)[i] = vv;
+    }
+}
+
+// ---- per-feature-row maintenance: decoder unit norm (+ shadows via wsae_prepare_launch) ----------
+// W_dT[h,:] /= max(||W_dT[h,:]||_2, 1e-12)   == F.normalize(decoder.weight, dim=0), column h
+__global__ void __launch_bounds__(256) rownorm_kernel(float* __restrict__ WdT, int H, int D) {
+    const int lane = threadIdx.x & 63;
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= H) return;
+    float* row = WdT + (int64_t)h * D;
+    float s = 0.f;
+    for (int d = lane * 2; d < D; d += 128) {
+        const float2 w = *(const float2*)(row + d);
+        s += w.x * w.x + w.y * w.y;
+    }
+    s = wave_sum(s);
+    const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+    for (int d = lane * 2; d < D; d += 128) {
+        float2 w = *(float2*)(row + d);
+        w.x *= inv;
+        w.y *= inv;
+        *(float2*)(row + d) = w;
+    }
+}
+
+extern "C" int wsae_normalize_decoder(wsae_ctx* ctx, float* params, void* stream) {
+    WSAE_REQUIRE(ctx && params, "wsae_normalize_decoder: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    rownorm_kernel<<<ceil_div(ctx->H, 4), 256, 0, st>>>(params + ctx->off[1], ctx->H, ctx->D);
+    WSAE_LAUNCH_CHECK();
+    return wsae_prepare_launch(ctx, params, st);
+}
+
+extern "C" int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                               float max_norm, float grad_scale, int32_t normalize_decoder, wsae_stats* stats,
+                               void* stream) {
+    WSAE_REQUIRE(ctx && params && grads && exp_avg && exp_avg_sq, "wsae_adamw_step: null argument");
+    WSAE_REQUIRE(step >= 1, "wsae_adamw_step: step is the 1-based update count, got %d", step);
+    WSAE_REQUIRE(ctx->P % 4 == 0, "wsae_adamw_step: pack size %lld not a multiple of 4", (long long)ctx->P);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n4 = ctx->P / 4;
+    const int nb = (int)min((int64_t)WSAE_MAX_PARTIALS, ceil_div64(n4, 256 * 2));
+    WSAE_PROF_BEGIN(ctx, WSAE_K_SQNORM, st);
+    sqnorm_kernel<<<nb, 256, 0, st>>>(grads, n4, grad_scale, ctx->part_sq);
+    WSAE_PROF_END(ctx, WSAE_K_SQNORM, st);
+    WSAE_LAUNCH_CHECK();
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const int nb2 = (int)min((int64_t)2048, ceil_div64(n4, 256));
+    WSAE_PROF_BEGIN(ctx, WSAE_K_ADAMW, st);
+    adamw_kernel<<<nb2, 256, 0, st>>>(params, grads, exp_avg, exp_avg_sq, n4, ctx->part_sq, nb, max_norm, grad_scale,
+                                      lr * weight_decay, beta1, beta2, eps, step_size, bc2_sqrt, stats);
+    WSAE_PROF_END(ctx, WSAE_K_ADAMW, st);
+    WSAE_LAUNCH_CHECK();
+    if (normalize_decoder) {
+        WSAE_PROF_BEGIN(ctx, WSAE_K_ROWNORM, st);
+        rownorm_kernel<<<ceil_div(ctx->H, 4), 256, 0, st>>>(params + ctx->off[1], ctx->H, ctx->D);
+        WSAE_PROF_END(ctx, WSAE_K_ROWNORM, st);
+        WSAE_LAUNCH_CHECK();
+    }
+    return wsae_prepare_launch(ctx, params, st);
+}
+
+// ---- dead features -------------------------------------------------------------------------------
+// mask[h] = (step_count - last_activated[h]) > threshold   (model.py:183-190, strict)
+__global__ void __launch_bounds__(1024)
+dead_scan_kernel(const int64_t* __restrict__ last, const int64_t* __restrict__ step_count, int64_t thr, int H,
+                 uint8_t* __restrict__ mask, wsae_stats* __restrict__ stats) {
+    __shared__ float red[16];
+    const int64_t step = *step_count;
+    int cnt = 0;
+    for (int h = threadIdx.x; h < H; h += 1024) {
+        const bool dead = (step - last[h]) > thr;
+        if (mask) mask[h] = dead ? 1 : 0;
+        cnt += dead ? 1 : 0;
+    }
+    const float t = block_sum((float)cnt, red);  // exact for H < 2^24
+    if (threadIdx.x == 0 && stats) {
+        stats->dead_count = (int32_t)t;
+        stats->dead_ratio = t / (float)H;
+    }
+}
+
+extern "C" int wsae_dead_scan(wsae_ctx* ctx, const int64_t* last_activated, const int64_t* step_count,
+                              int64_t threshold, uint8_t* mask, wsae_stats* stats, void* stream) {
+    WSAE_REQUIRE(ctx && last_activated && step_count, "wsae_dead_scan: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    WSAE_PROF_BEGIN(ctx, WSAE_K_DEAD_SCAN, st);
+    dead_scan_kernel<<<1, 1024, 0, st>>>(last_activated, step_count, threshold, ctx->H, mask, stats);
+    WSAE_PROF_END(ctx, WSAE_K_DEAD_SCAN, st);
+    WSAE_LAUNCH_CHECK();
+    return WSAE_OK;
+}
+
+// row_err[b] = sum_d (x[b,d] - recon[b,d])^2      (model.py:230-231)
+template <int XDT>
+__global__ void __launch_bounds__(256) row_err_kernel(const void* __restrict__ x, const int32_t* __restrict__ rows,
+                                                      const float* __restrict__ recon, int B, int D,
+                                                      float* __restrict__ row_err) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t src = rows ? (int64_t)rows[b] : (int64_t)b;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float r = load_act<XDT>(x, src * D + d) - recon[(int64_t)b * D + d];
+        s = fmaf(r, r, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) row_err[b] = s;
+}
+
+extern "C" int wsae_row_errors(wsae_ctx* ctx, const void* x, int32_t x_dtype, const int32_t* rows, const float* recon,
+                               int32_t B, float* row_err, void* stream) {
+    WSAE_REQUIRE(ctx && x && recon && row_err && B >= 1, "wsae_row_errors: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == WSAE_DT_F32)
+        row_err_kernel<WSAE_DT_F32><<<ceil_div(B, 4), 256, 0, st>>>(x, rows, recon, B, ctx->D, row_err);
+    else
+        row_err_kernel<WSAE_DT_BF16><<<ceil_div(B, 4), 256, 0, st>>>(x, rows, recon, B, ctx->D, row_err);
+    WSAE_LAUNCH_CHECK();
+    return WSAE_OK;
+}
+
+// dead list: ascending indices of mask != 0, at most cap (single block, ordered compaction)
+__global__ void __launch_bounds__(1024) dead_list_kernel(const uint8_t* __restrict__ mask, int H, int cap,
+                                                         int32_t* __restrict__ list, int32_t* __restrict__ n_out) {
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int h0 = 0; h0 < H; h0 += 1024) {
+        const int h = h0 + threadIdx.x;
+        const bool on = h < H && mask[h] != 0;
+        const unsigned long long bm = __ballot(on);
+        if (lane == 0) wave_cnt[wave] = __popcll(bm);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        const int pos = off + __popcll(bm & ((1ull << lane) - 1ull));
+        if (on && pos < cap) list[pos] = h;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wave_cnt[w];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = min(base_s, cap);
+}
+
+// rows by error descending (ties: lower row first): single-block bitonic sort of 64-bit keys in LDS
+__global__ void __launch_bounds__(1024) sort_rows_kernel(const float* __restrict__ row_err, int Br, int npow2,
+                                                         int32_t* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* key = (uint64_t*)smem;
+    for (int i = threadIdx.x; i < npow2; i += 1024) {
+        uint64_t k = 0;
+        if (i < Br) {
+            const uint32_t u = __float_as_uint(row_err[i]);
+            const uint32_t o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            k = ((uint64_t)o << 32) | (uint32_t)(~(uint32_t)i);
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= npow2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < npow2; i += 1024) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool desc = (i & size) == 0;
+                    const uint64_t a = key[i], b = key[j];
+                    if ((a < b) == desc) {
+                        key[i] = b;
+                        key[j] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < Br; i += 1024) order[i] = (int32_t)(~(uint32_t)key[i]);
+}
+
+// rewrite dead feature i with the i-th highest-error input row, L2-normalised (model.py:237-255)
+template <int XDT>
+__global__ void __launch_bounds__(256)
+resample_write_kernel(const void* __restrict__ inputs, const int32_t* __restrict__ rows, int Br, int D,
+                      const int32_t* __restrict__ dead_list, const int32_t* __restrict__ n_dead,
+                      const int32_t* __restrict__ order, float* __restrict__ We, float* __restrict__ WdT,
+                      float* __restrict__ be, int64_t* __restrict__ last, const int64_t* __restrict__ step_count) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(*n_dead, Br);
+    if (i >= n) return;
+    const int f = dead_list[i];
+    const int r = order[i];
+    const int64_t src = rows ? (int64_t)rows[r] : (int64_t)r;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float v = load_act<XDT>(inputs, src * D + d);
+        s = fmaf(v, v, s);
+    }
+    s = wave_sum(s);
+    const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+    for (int d = lane; d < D; d += 64) {
+        const float v = load_act<XDT>(inputs, src * D + d) * inv;
+        We[(int64_t)f * D + d] = v;
+        WdT[(int64_t)f * D + d] = v;
+    }
+    if (lane == 0) {
+        be[f] = 0.f;
+        last[f] = *step_count;
+    }
+}
+
+extern "C" int wsae_resample_dead(wsae_ctx* ctx, float* params, const void* inputs, int32_t x_dtype,
+                                  const int32_t* rows, int32_t Br, const float* row_err, const uint8_t* dead_mask,
+                                  int64_t* last_activated, const int64_t* step_count, int32_t num_cap,
+                                  int32_t* n_dead_out, void* stream) {
+    WSAE_REQUIRE(ctx && params && inputs && row_err && dead_mask && last_activated && step_count && n_dead_out,
+                 "wsae_resample_dead: null argument");
+    WSAE_REQUIRE(Br >= 1, "wsae_resample_dead: empty resample batch");
+    hipStream_t st = (hipStream_t)stream;
+    const int H = ctx->H, D = ctx->D;
+    int npow2 = 1;
+    while (npow2 < Br) npow2 <<= 1;
+    WSAE_REQUIRE((size_t)npow2 * 8 <= 128 * 1024, "resample batch %d too large (max 16384 rows)", Br);
+    WSAE_REQUIRE(Br <= ctx->maxB, "resample batch %d exceeds max_batch %d", Br, ctx->maxB);
+    const int cap = num_cap >= 0 ? min(num_cap, H) : H;
+    dead_list_kernel<<<1, 1024, 0, st>>>(dead_mask, H, cap, ctx->dead_list, n_dead_out);
+    WSAE_LAUNCH_CHECK();
+    sort_rows_kernel<<<1, 1024, (size_t)npow2 * 8, st>>>(row_err, Br, npow2, ctx->row_order);
+    WSAE_LAUNCH_CHECK();
+    const int nwork = min(cap, Br);
+    if (nwork > 0) {
+        float* We = params + ctx->off[0];
+        float* WdT = params + ctx->off[1];
+        float* be = params + ctx->off[2];
+        if (x_dtype == WSAE_DT_F32)
+            resample_write_kernel<WSAE_DT_F32><<<ceil_div(nwork, 4), 256, 0, st>>>(
+                inputs, rows, Br, D, ctx->dead_list, n_dead_out, ctx->row_order, We, WdT, be, last_activated, step_count);
+        else
+            resample_write_kernel<WSAE_DT_BF16><<<ceil_div(nwork, 4), 256, 0, st>>>(
+                inputs, rows, Br, D, ctx->dead_list, n_dead_out, ctx->row_order, We, WdT, be, last_activated, step_count);
+        WSAE_LAUNCH_CHECK();
+    }
+    return wsae_prepare_launch(ctx, params, st);
+}

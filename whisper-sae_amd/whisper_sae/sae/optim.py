@@ -1,0 +1,99 @@
+"""``FusedAdamW``: a ``torch.optim.Optimizer`` whose ``step`` is one pass of HIP kernels over the flat
+parameter pack: global-L2 clip -> AdamW -> decoder column renorm -> bf16 shadow refresh
+(reference: ``clip_grad_norm_`` + ``AdamW.step`` + ``normalize_decoder_weights``,
+training.py:186-198; AdamW semantics of torch).
+
+It keeps torch's optimizer surface so that the reference's LR schedulers
+(``LinearLR``/``CosineAnnealingLR``/``SequentialLR``) drive ``param_groups[0]["lr"]`` unchanged and
+``state_dict()`` has the layout of ``torch.optim.AdamW`` (per-parameter ``step`` / ``exp_avg`` /
+``exp_avg_sq`` in ``module.parameters()`` order), i.e. checkpoints are interchangeable.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch.optim import Optimizer
+
+from .. import _native as N
+
+
+class FusedAdamW(Optimizer):
+    def __init__(self, module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("invalid AdamW hyper-parameter")
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None,
+                        decoupled_weight_decay=True)
+        super().__init__(list(module.parameters()), defaults)
+        self.module = module
+        self._t = 0  # number of updates applied
+        self._m = None  # flat exp_avg / exp_avg_sq in pack layout
+        self._v = None
+        self.grads = None  # flat gradient pack the backward kernels fill
+
+    # -- flat state ------------------------------------------------------------------------------
+    def _ensure_state(self, eng) -> None:
+        if self._m is not None and self._m.device == eng.device and self._m.numel() == eng.P:
+            return
+        self._m = torch.zeros(eng.P, dtype=torch.float32, device=eng.device)
+        self._v = torch.zeros(eng.P, dtype=torch.float32, device=eng.device)
+        self.grads = torch.zeros(eng.P, dtype=torch.float32, device=eng.device)
+        self._alias_state(eng)
+
+    def _alias_state(self, eng) -> None:
+        """Point every parameter's exp_avg / exp_avg_sq at its slice of the flat buffers, carrying
+        over values that were loaded (``load_state_dict``) or lived on another device."""
+        named = self.module._named_core_params()
+        by_id = {id(p): name for name, p in named.items()}
+        for p in self.param_groups[0]["params"]:
+            name = by_id.get(id(p))
+            if name is None:
+                continue
+            st = self.state[p]
+            for key, flat in (("exp_avg", self._m), ("exp_avg_sq", self._v)):
+                view = eng.view(name, flat)
+                old = st.get(key)
+                if old is not None and old.data_ptr() != view.data_ptr():
+                    view.copy_(old.to(device=eng.device, dtype=torch.float32))
+                st[key] = view
+            st["step"] = torch.tensor(float(self._t))
+
+    def grad_view(self, name: str) -> torch.Tensor:
+        return self.module._engine.view(name, self.grads)
+
+    # -- Optimizer API ---------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = True) -> None:  # gradients live in self.grads, overwritten each step
+        super().zero_grad(set_to_none=set_to_none)
+
+    @torch.no_grad()
+    def step(self, closure=None, *, precision: int = N.PREC_FP32, max_norm: float = 0.0, grad_scale: float = 1.0,
+             normalize_decoder: bool = False, batch: int = 64):
+        """Apply one update from ``self.grads`` (filled by ``wsae_weight_grads``)."""
+        if closure is not None:
+            raise NotImplementedError("FusedAdamW does not take a closure")
+        eng = self.module.bind()
+        self._ensure_state(eng)
+        g = self.param_groups[0]
+        self._t += 1
+        handle = eng.ctx(precision, batch)
+        N.check(eng.lib.wsae_adamw_step(handle, eng.pack.data_ptr(), self.grads.data_ptr(), self._m.data_ptr(),
+                                        self._v.data_ptr(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                        float(g["eps"]), float(g["weight_decay"]), self._t, float(max_norm),
+                                        float(grad_scale), 1 if normalize_decoder else 0, eng.stats.data_ptr(),
+                                        eng.stream()), "wsae_adamw_step")
+        eng.mark_fresh(precision)
+        for st in self.state.values():
+            if "step" in st:
+                st["step"].fill_(float(self._t))
+        return None
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
+        self._t = int(max(steps)) if steps else 0
+        eng = getattr(self.module, "_engine", None)
+        if eng is not None:  # otherwise the first step() binds and carries the loaded moments over
+            if self._m is None or self._m.device != eng.device:
+                self._ensure_state(eng)
+            else:
+                self._alias_state(eng)

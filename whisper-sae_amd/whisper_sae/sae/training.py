@@ -1,0 +1,317 @@
+"""``SAETrainer`` for MI355X -- the reference's trainer surface (src/whisper_sae/sae/training.py)
+on top of the fused HIP train step.
+
+One ``train_step`` = stage batch -> encode GEMM (MFMA) -> TopK -> sparse decode + MSE + dpre ->
+weight-gradient GEMMs (MFMA) -> [RCCL all-reduce under torch.distributed] -> clip + AdamW + decoder
+renorm -> dead-feature scan, all enqueued on the current HIP stream without a host sync.  The
+per-step scalars are written by the kernels into a device record and copied asynchronously to
+pinned host memory; ``TrainingMetrics`` fields read them lazily, so the five ``.item()`` syncs of
+the reference step (training.py:207-213) only happen if and when somebody looks at the numbers.
+
+Documented divergences from the reference:
+* autocast dtype is bf16 (MFMA) instead of fp16 + loss scaling; ``trainer.scaler`` is kept as a
+  disabled ``GradScaler`` so attribute access keeps working;
+* dead-feature resampling, which the reference defines but never calls, runs after the step
+  counter advances when ``resample_dead=True`` is passed (``scripts/train.py`` passes
+  ``config.sae.dead_feature_resample``);
+* models without dead-feature tracking (``ReLUSAE``) report ``dead_feature_ratio = 0`` instead
+  of raising ``AttributeError``.
+"""
+
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, fields
+from pathlib import Path
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
+
+from .. import _native as N
+from ..config import TrainingConfig
+from .engine import _dtype_code, require_device_tensor
+from .optim import FusedAdamW
+
+
+@dataclass
+class TrainingMetrics:
+    """Scalars of one training step (field set of the reference, training.py:19-29)."""
+
+    loss: float
+    reconstruction_loss: float
+    sparsity_loss: float
+    l0: float
+    dead_feature_ratio: float
+    learning_rate: float
+    step: int
+
+
+class _PendingMetrics(TrainingMetrics):
+    """``TrainingMetrics`` whose device-produced fields are fetched on first access.
+
+    The values sit in a pinned host record that an async D2H copy fills; reading any of them
+    synchronises the producing stream once and then caches plain floats.
+    """
+
+    _LAZY = ("loss", "reconstruction_loss", "sparsity_loss", "l0", "dead_feature_ratio")
+
+    def __init__(self, record: Tensor, stream, learning_rate: float, step: int):  # noqa: D401 - no dataclass init
+        object.__setattr__(self, "_record", record)
+        object.__setattr__(self, "_stream", stream)
+        object.__setattr__(self, "learning_rate", learning_rate)
+        object.__setattr__(self, "step", step)
+
+    def _resolve(self) -> None:
+        rec = self.__dict__.pop("_record", None)
+        if rec is None:
+            return
+        self.__dict__.pop("_stream").synchronize()
+        f = rec.view(torch.float32)
+        self.__dict__.update(loss=float(f[0]), reconstruction_loss=float(f[0]), sparsity_loss=0.0, l0=float(f[1]),
+                             dead_feature_ratio=float(f[4]), grad_norm=float(f[2]), clip_coef=float(f[3]))
+
+    def __getattr__(self, name):  # only reached for attributes not yet in __dict__
+        if name in _PendingMetrics._LAZY or name in ("grad_norm", "clip_coef"):
+            self._resolve()
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+
+class _MetricsRing:
+    """Pinned host records for the async copies of the device step record."""
+
+    def __init__(self, chunk: int = 4096):
+        self.chunk = chunk
+        self.buf = None
+        self.used = 0
+
+    def next(self) -> Tensor:
+        if self.buf is None or self.used == self.chunk:
+            self.buf = torch.zeros(self.chunk, N.STATS_WORDS, dtype=torch.int32).pin_memory()
+            self.used = 0
+        rec = self.buf[self.used]
+        self.used += 1
+        return rec
+
+
+class SAETrainer:
+    """Trains a sparse autoencoder on activation batches (reference training.py:32-379)."""
+
+    def __init__(self, model, config: TrainingConfig, device="cpu", run_dir: Optional[Path] = None,
+                 resample_dead_every: int = 5000, resample_batch_size: int = 8192, resample_dead: bool = False):
+        self.model = model.to(device)
+        self.config = config
+        self.device = device
+        self.run_dir = Path(run_dir) if run_dir is not None else Path("outputs")
+        self.run_dir.mkdir(parents=True, exist_ok=True)
+        self.resample_dead_every = resample_dead_every
+        self.resample_batch_size = resample_batch_size
+        self.resample_dead = resample_dead
+
+        self.optimizer = FusedAdamW(model, lr=config.learning_rate, weight_decay=config.weight_decay)
+        self.scheduler = None
+
+        on_gpu = str(device).startswith("cuda")
+        self.use_amp = bool(config.use_amp and on_gpu)  # bf16 MFMA contractions when set, fp32 MFMA otherwise
+        self.scaler = torch.amp.GradScaler("cuda", enabled=False)  # bf16 needs no loss scaling
+
+        self.global_step = 0
+        self.epoch = 0
+        self.metrics_history: list[TrainingMetrics] = []
+        self.num_resampled_total = 0
+        self.wandb_run = None
+        self._resample_dataset = None
+        self._records = _MetricsRing()
+        self._tracks_dead = hasattr(model, "get_dead_feature_ratio")
+
+    # -- resampling (reference training.py:89-134; see module docstring) ---------------------------
+    def set_resample_dataset(self, dataset) -> None:
+        self._resample_dataset = dataset
+
+    def _maybe_resample_dead_features(self) -> int:
+        ds = self._resample_dataset
+        if ds is None or not hasattr(self.model, "resample_dead_features"):
+            return 0
+        if self.global_step == 0 or self.global_step % self.resample_dead_every != 0:
+            return 0
+        n = len(ds)
+        take = torch.randperm(n)[: self.resample_batch_size]
+        tensors = getattr(ds, "tensors", None)
+        if tensors is not None:  # TensorDataset: one indexed gather instead of per-item __getitem__
+            batch = tensors[0][take]
+        else:
+            items = [ds[int(i)] for i in take]
+            batch = torch.stack([it[0] if isinstance(it, (tuple, list)) else it for it in items])
+        count = self.model.resample_dead_features(batch.to(self.device))
+        self.num_resampled_total += count
+        if count > 0 and self.wandb_run is not None:
+            self.wandb_run.log({"train/features_resampled": count}, step=self.global_step)
+        return count
+
+    # -- learning-rate schedule (reference training.py:136-159): torch's own scheduler classes --------
+    def setup_scheduler(self, total_steps: int) -> None:
+        warm = min(self.config.warmup_steps, total_steps // 10)
+        ramp = LinearLR(self.optimizer, start_factor=0.01, end_factor=1.0, total_iters=warm)
+        decay = CosineAnnealingLR(self.optimizer, T_max=total_steps - warm, eta_min=0.1 * self.config.learning_rate)
+        self.scheduler = SequentialLR(self.optimizer, schedulers=[ramp, decay], milestones=[warm])
+
+    # -- the step ------------------------------------------------------------------------------------
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist, dist.get_world_size()
+        return None, 1
+
+    def train_step(self, batch) -> TrainingMetrics:
+        """One optimisation step on ``batch`` ([B, D] tensor, or a tuple/list whose first item is one).
+
+        ``batch`` may also be ``(ring_data, row_indices)`` produced by ``ActivationRing.batch``: then
+        the kernels gather the rows straight from the on-device ring buffer.
+        """
+        model = self.model
+        model.train()
+        rows = None
+        if isinstance(batch, RingBatch):
+            x, rows = batch.data, batch.rows
+        else:
+            if isinstance(batch, (tuple, list)):
+                batch = batch[0]
+            x = batch.to(self.device, non_blocking=True)
+        require_device_tensor(x, "batch")
+        if not hasattr(model, "bind"):
+            raise N.WsaeError(f"{type(model).__name__} has no fused MI355X train step in this build")
+        eng = model.bind()
+        lib, st = eng.lib, eng.stream()
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = x.contiguous()
+        B = int(rows.numel()) if rows is not None else x.shape[0]
+        prec = N.PREC_BF16 if self.use_amp else N.PREC_FP32
+        token = model.param_token()
+        if token != getattr(self, "_token", None):
+            eng.invalidate()
+        handle = eng.prepare(prec, B)
+        opt = self.optimizer
+        opt._ensure_state(eng)
+        w = eng.work(B)
+        pk, xd, rp = eng.pack.data_ptr(), _dtype_code(x), N.ptr(rows)
+        stats = eng.stats.data_ptr()
+        step_ptr = model.step_count.data_ptr()
+        N.check(lib.wsae_encode_topk(handle, pk, x.data_ptr(), xd, rp, B, w["vals"].data_ptr(), w["idx"].data_ptr(),
+                                     step_ptr, stats, st), "wsae_encode_topk")
+        N.check(lib.wsae_decode_loss(handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(), B, 0,
+                                     1, w["dpre"].data_ptr(), model.feature_last_activated.data_ptr(), step_ptr, stats,
+                                     st), "wsae_decode_loss")
+        N.check(lib.wsae_weight_grads(handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(),
+                                      w["dpre"].data_ptr(), B, opt.grads.data_ptr(), st), "wsae_weight_grads")
+        eng.generation += 1
+        dist, world = self._world()
+        if dist is not None:  # data parallel: mean of the per-rank mean-gradients, agreed dead-feature clock
+            dist.all_reduce(opt.grads, op=dist.ReduceOp.SUM)
+            dist.all_reduce(model.feature_last_activated, op=dist.ReduceOp.MAX)
+        opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=1.0 / world,
+                 normalize_decoder=True, batch=B)
+        self._token = model.param_token()
+        lr_used = opt.param_groups[0]["lr"]
+        if self.scheduler is not None:
+            self.scheduler.step()
+        self.global_step += 1
+        N.check(lib.wsae_dead_scan(handle, model.feature_last_activated.data_ptr(), step_ptr,
+                                   int(model.dead_feature_threshold), 0, stats, st), "wsae_dead_scan")
+        rec = self._records.next()
+        rec.copy_(eng.stats, non_blocking=True)
+        metrics = _PendingMetrics(rec, torch.cuda.current_stream(eng.device), opt.param_groups[0]["lr"],
+                                  self.global_step)
+        del lr_used
+        if self.resample_dead:
+            self._maybe_resample_dead_features()
+        return metrics
+
+    def train_epoch(self, dataloader, progress=None, task_id=None) -> list:
+        """One pass over ``dataloader`` (reference training.py:219-259)."""
+        seen = []
+        for batch in dataloader:
+            m = self.train_step(batch)
+            seen.append(m)
+            self.metrics_history.append(m)
+            if progress is not None and task_id is not None:
+                progress.update(task_id, advance=1)
+            if self.wandb_run is not None and self.global_step % 100 == 0:
+                self.wandb_run.log({"train/loss": m.loss, "train/reconstruction_loss": m.reconstruction_loss,
+                                    "train/l0": m.l0, "train/dead_ratio": m.dead_feature_ratio,
+                                    "train/lr": m.learning_rate}, step=self.global_step)
+        self.epoch += 1
+        return seen
+
+    def train(self, dataloader, epochs: Optional[int] = None, checkpoint_every: Optional[int] = None) -> None:
+        """Full loop with LR schedule, progress display and checkpoints (reference training.py:261-316)."""
+        from rich.progress import BarColumn, Progress, SpinnerColumn, TaskProgressColumn, TextColumn
+
+        epochs = epochs or self.config.epochs
+        checkpoint_every = checkpoint_every or self.config.checkpoint_every
+        steps_per_epoch = len(dataloader)
+        self.setup_scheduler(steps_per_epoch * epochs)
+        columns = (SpinnerColumn(), TextColumn("[progress.description]{task.description}"), BarColumn(),
+                   TaskProgressColumn())
+        with Progress(*columns) as progress:
+            outer = progress.add_task(f"[cyan]Training {epochs} epochs", total=epochs)
+            for e in range(1, epochs + 1):
+                inner = progress.add_task(f"[green]Epoch {e}/{epochs}", total=steps_per_epoch)
+                ms = self.train_epoch(dataloader, progress, inner)
+                mean_loss = sum(m.loss for m in ms) / len(ms)
+                mean_l0 = sum(m.l0 for m in ms) / len(ms)
+                progress.remove_task(inner)
+                progress.update(outer, advance=1)
+                progress.console.print(f"Epoch {e}: loss={mean_loss:.4f}, L0={mean_l0:.1f}, "
+                                       f"dead={ms[-1].dead_feature_ratio:.1%}")
+                if e % checkpoint_every == 0:
+                    self.save_checkpoint(f"checkpoint_epoch{e}.pt")
+        self.save_checkpoint("final.pt")
+
+    # -- persistence (reference training.py:318-379: same keys, same file formats) --------------------
+    def save_checkpoint(self, filename: str) -> Path:
+        target = self.run_dir / filename
+        payload = {
+            "model_state_dict": {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+            "optimizer_state_dict": self.optimizer.state_dict(),
+            "scheduler_state_dict": self.scheduler.state_dict() if self.scheduler else None,
+            "global_step": self.global_step,
+            "epoch": self.epoch,
+            "config": self.config.model_dump(),
+        }
+        torch.save(payload, target)
+        return target
+
+    def load_checkpoint(self, path) -> None:
+        ckpt = torch.load(path, map_location=self.device)
+        self.model.load_state_dict(ckpt["model_state_dict"])
+        self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+        if ckpt["scheduler_state_dict"] and self.scheduler:
+            self.scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+        self.global_step = ckpt["global_step"]
+        self.epoch = ckpt["epoch"]
+
+    def save_metrics(self, filename: str = "metrics.json") -> Path:
+        target = self.run_dir / filename
+        keys = ("step", "loss", "reconstruction_loss", "sparsity_loss", "l0", "dead_feature_ratio", "learning_rate")
+        rows = [{k: getattr(m, k) for k in keys} for m in self.metrics_history]
+        target.write_text(json.dumps(rows, indent=2))
+        return target
+
+
+class RingBatch:
+    """A batch that lives in the on-device ring: (ring storage, int32 row indices on the same device)."""
+
+    __slots__ = ("data", "rows")
+
+    def __init__(self, data: Tensor, rows: Tensor):
+        self.data, self.rows = data, rows
+
+    def __len__(self) -> int:
+        return int(self.rows.numel())
+
+
+assert {f.name for f in fields(TrainingMetrics)} == {"loss", "reconstruction_loss", "sparsity_loss", "l0",
+                                                      "dead_feature_ratio", "learning_rate", "step"}
