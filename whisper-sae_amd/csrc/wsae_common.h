@@ -52,6 +52,8 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // number of partial-sum slots every reduction in the library uses (one per producing block,
 // blocks beyond it fold round-robin): fixed so that the reduction order is deterministic.
 #define WSAE_MAX_PARTIALS 1024
+// split-K factor of the weight-gradient contractions: one batch range per XCD
+#define WSAE_WGRAD_MAX_SPLIT 8
 
 struct wsae_prof {
     unsigned mask;                      // bit per kernel id
@@ -79,6 +81,9 @@ struct wsae_ctx {
     float* part_dbd;      // [WSAE_MAX_PARTIALS][D]
     float* part_sq;       // [WSAE_MAX_PARTIALS]
     float* colnorm;       // [H] decoder column sum of squares scratch
+    float* wg_slabs;      // [WSAE_WGRAD_MAX_SPLIT][2*H*D] split-K partial weight gradients
+    float* dbe_slab;      // [WSAE_WGRAD_MAX_SPLIT][H]
+    float* dbpre_part;    // [ceil(H/32)][D]
     int32_t* counters;    // small int scratch (fallback rows, dead count, resample cursors)
     int32_t* dead_list;   // [H] compacted dead feature indices (resample)
     int32_t* row_order;   // [maxB] rows sorted by error (resample)

@@ -11,27 +11,34 @@
 // scatter of the entries whose feature falls in the tile) and runs it through the same NT MFMA
 // slab code as the encode GEMM.  The right operands are the transposed batch operands xT / gT
 // left in the ctx by the encode and decode launches.
+//
+// Split-K over the batch: workgroup id = tile * nsplit + split, so with nsplit = 8 the round-robin
+// workgroup->XCD dealing puts every tile of one batch range on one XCD, whose 4 MB L2 then holds
+// that range's xT/gT columns and compact code (2048 rows at cfg2 = 3.6 MB): each XCD streams its
+// share of the batch from HBM once and the 144 tiles re-read it from L2.  Every split writes a
+// private fp32 slab; a second kernel sums the slabs in fixed order (deterministic, no float atomics).
 #include "wsae_common.h"
 #include "wsae_mfma.h"
 
-template <typename T>
+template <typename T, int EPT>
 __global__ void __launch_bounds__(256)
 wgrad_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, const float* __restrict__ dpre,
              const T* __restrict__ xT, const T* __restrict__ gT, int B, int ldT, int H, int D, int K, int nsplit,
-             float* __restrict__ dWe, float* __restrict__ dWdT, float* __restrict__ dbe) {
+             int ntm, int ntn, float* __restrict__ out, int64_t slab_stride, float* __restrict__ dbe_slab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
     char* Bs = smem + TILE_LDS_BYTES;
-    float* dbe_s = (float*)(smem + 2 * TILE_LDS_BYTES);  // [128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int f0 = blockIdx.x * TILE_M, d0 = blockIdx.y * TILE_N;
-    const int which = blockIdx.z / nsplit;  // 0: dW_dT (hidden, g)   1: dW_e (dpre, x_c)
-    const int split = blockIdx.z % nsplit;
+    const int split = blockIdx.x % nsplit;
+    int tile = blockIdx.x / nsplit;
+    const int which = tile / (ntm * ntn);  // 0: dW_dT (hidden, g)   1: dW_e (dpre, x_c)
+    tile -= which * ntm * ntn;
+    const int f0 = (tile / ntn) * TILE_M, d0 = (tile % ntn) * TILE_N;
     constexpr int KT = Mfma<T>::KT;
     const T* Bt = which == 0 ? gT : xT;
     const float* sv = which == 0 ? vals : dpre;
-    const bool do_dbe = (which == 1) && (blockIdx.y == 0);
+    const bool do_dbe = (which == 1) && (d0 == 0);
 
     const int nchunks = (B + KT - 1) / KT;
     const int per = (nchunks + nsplit - 1) / nsplit;
@@ -44,39 +51,60 @@ wgrad_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, co
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (tid < 128) dbe_s[tid] = 0.f;
+    float dbe_acc = 0.f;  // thread t < 128 owns feature row f0 + t
 
     SlabRegs<T> rb;
-    if (c_begin < c_end) slab_load<T>(rb, Bt, ldT, d0, D, c_begin * KT, ldT, tid);
-    for (int ck = c_begin; ck < c_end; ++ck) {
+    int ef[EPT];
+    float ev[EPT];
+    auto load_entries = [&](int ck) {
         const int b0 = ck * KT;
+        const int nent = min(KT, B - b0) * K;
+        const int64_t base = (int64_t)b0 * K;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + 256 * i;
+            const bool ok = e < nent;
+            ef[i] = ok ? idx[base + e] - f0 : -1;
+            ev[i] = ok ? sv[base + e] : 0.f;
+        }
+    };
+    if (c_begin < c_end) {
+        slab_load<T>(rb, Bt, ldT, d0, D, c_begin * KT, ldT, tid);
+        load_entries(c_begin);
+    }
+    for (int ck = c_begin; ck < c_end; ++ck) {
         // zero the sparse slice, stage the dense one
         for (int c = tid; c < TILE_LDS_BYTES / 16; c += 256) *(uint4*)(As + c * 16) = make_uint4(0, 0, 0, 0);
         slab_store<T>(rb, Bs, tid);
         __syncthreads();
-        if (ck + 1 < c_end) slab_load<T>(rb, Bt, ldT, d0, D, (ck + 1) * KT, ldT, tid);
-        // scatter the compact entries of rows [b0, b0+KT) whose feature lies in [f0, f0+128)
-        const int nrow = min(KT, B - b0);
-        const int nent = nrow * K;
-        const int64_t base = (int64_t)b0 * K;
-        for (int e = tid; e < nent; e += 256) {
-            const int f = idx[base + e] - f0;
+        // scatter the prefetched compact entries of rows [b0, b0+KT) whose feature lies in [f0, f0+128)
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int f = ef[i];
             if ((unsigned)f < 128u) {
-                float v = sv[base + e];
+                float v = ev[i];
                 if (which == 0) v = v > 0.f ? v : 0.f;  // hidden = relu(topk value)
-                if (v != 0.f) {
-                    const int bl = e / K;
-                    *(T*)(As + f * LDS_ROW_BYTES + bl * (int)sizeof(T)) = (T)v;
-                    if (do_dbe) atomicAdd(&dbe_s[f], v);
-                }
+                const int bl = (tid + 256 * i) / K;
+                if (v != 0.f) *(T*)(As + f * LDS_ROW_BYTES + bl * (int)sizeof(T)) = (T)v;
             }
         }
+        if (ck + 1 < c_end) {  // next chunk's operands fly during the MFMAs
+            slab_load<T>(rb, Bt, ldT, d0, D, (ck + 1) * KT, ldT, tid);
+            load_entries(ck + 1);
+        }
         __syncthreads();
+        if (do_dbe && tid < 128) {  // db_e: row sums of the slice, fixed order
+            const T* row = (const T*)(As + tid * LDS_ROW_BYTES);
+            float s = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < KT; ++k) s += (float)row[k];
+            dbe_acc += s;
+        }
         Mfma<T>::slab(As, Bs, wm * 64, wn * 64, lane, acc);
         __syncthreads();
     }
 
-    float* out = which == 0 ? dWdT : dWe;
+    float* dst = out + (int64_t)split * slab_stride + (which == 0 ? (int64_t)H * D : 0);
     const int col = lane & 31, rq = lane >> 5;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -87,57 +115,92 @@ wgrad_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int f = f0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-                if (f < H) {
-                    const float v = acc[mi][ni][r];
-                    if (nsplit == 1)
-                        out[(int64_t)f * D + d] = v;
-                    else if (v != 0.f)
-                        atomicAdd(out + (int64_t)f * D + d, v);
-                }
+                if (f < H) dst[(int64_t)f * D + d] = acc[mi][ni][r];
             }
         }
-    if (do_dbe && tid < 128 && f0 + tid < H) {
-        const float v = dbe_s[tid];
-        if (v != 0.f) atomicAdd(dbe + f0 + tid, v);
+    if (do_dbe && tid < 128 && f0 + tid < H) dbe_slab[(int64_t)split * H + f0 + tid] = dbe_acc;
+}
+
+// grads[W parts] = sum over splits of the slabs (fixed order); db_e likewise; in BF16 mode the
+// rank-1 correction of the folded pre-bias is applied on the way:
+//   dW_e[h,:] -= db_e[h] * b_pre      (the MFMA contraction saw raw x, not x - b_pre)
+template <bool FOLD>
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, const float* __restrict__ dbe_slab, int nsplit,
+                    const float* __restrict__ bpre, float* __restrict__ grads, float* __restrict__ dbe_out, int H, int D) {
+    const int64_t n4 = (int64_t)2 * H * D / 4;
+    const int64_t hd4 = (int64_t)H * D / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 a = ((const float4*)slabs)[i];
+        for (int s = 1; s < nsplit; ++s) {
+            const float4 b = ((const float4*)(slabs + s * slab_stride))[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (i < hd4) {  // dW_e segment
+            const int64_t e = i * 4;
+            const int h = (int)(e / D), d = (int)(e - (int64_t)h * D);
+            float be = 0.f;
+            for (int s = 0; s < nsplit; ++s) be += dbe_slab[(int64_t)s * H + h];
+            if (d == 0) dbe_out[h] = be;
+            if (FOLD) {
+                const float4 bp = *(const float4*)(bpre + d);
+                a.x -= be * bp.x; a.y -= be * bp.y; a.z -= be * bp.z; a.w -= be * bp.w;
+            }
+        }
+        ((float4*)grads)[i] = a;
     }
 }
 
-// db_d, db_pre and (BF16 mode) the rank-1 correction of the folded pre-bias:
-//   db_pre = db_d - W^T db_e            (W = the encoder weights the forward actually used)
-//   dW_e[h,:] -= db_e[h] * b_pre        (BF16 mode: the MFMA contraction saw raw x, not x - b_pre)
-// One block per 32 feature rows; partial GEMV sums join db_pre by float atomics.
-template <typename TW, bool FOLD>
-__global__ void __launch_bounds__(256)
-bias_grads_kernel(const TW* __restrict__ W, const float* __restrict__ bpre, const float* __restrict__ dbd_acc,
-                  float* __restrict__ dWe, const float* __restrict__ dbe, float* __restrict__ dbd,
-                  float* __restrict__ dbpre, int H, int D) {
+// db_pre partials: part[blk][d] = sum_{h in blk's 32 rows} db_e[h] * W[h][d]   (no atomics)
+template <typename TW>
+__global__ void __launch_bounds__(256) dbpre_partial_kernel(const TW* __restrict__ W, const float* __restrict__ dbe,
+                                                            float* __restrict__ part, int H, int D) {
     __shared__ float e_s[32];
     const int h0 = blockIdx.x * 32;
     if (threadIdx.x < 32) e_s[threadIdx.x] = (h0 + (int)threadIdx.x < H) ? dbe[h0 + threadIdx.x] : 0.f;
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256) {
         float a = 0.f;
-        const float bp = bpre[d];
-#pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-            const int h = h0 + i;
-            if (h < H) {
-                const float e = e_s[i];
-                a = fmaf(e, (float)W[(int64_t)h * D + d], a);
-                if (FOLD && e != 0.f) dWe[(int64_t)h * D + d] -= e * bp;
-            }
-        }
-        float add = -a;
-        if (blockIdx.x == 0) {
-            const float s = dbd_acc[d];
-            dbd[d] = s;
-            add += s;
-        }
-        if (add != 0.f) atomicAdd(dbpre + d, add);
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i)
+            if (h0 + i < H) a = fmaf(e_s[i], (float)W[(int64_t)(h0 + i) * D + d], a);
+        part[(int64_t)blockIdx.x * D + d] = a;
     }
 }
 
-// (sum_b g was accumulated by the decode launch into the [D] accumulator at the head of part_dbd.)
+// db_d = sum_b g (accumulated by the decode launch); db_pre = db_d - sum_blk part[blk]
+__global__ void __launch_bounds__(256) bias_finish_kernel(const float* __restrict__ dbd_acc, const float* __restrict__ part,
+                                                          int nblk, float* __restrict__ dbd, float* __restrict__ dbpre,
+                                                          int D) {
+    __shared__ float red[4][64];
+    const int dl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + dl;
+    float a = 0.f;
+    if (d < D)
+        for (int b = grp; b < nblk; b += 4) a += part[(int64_t)b * D + d];
+    red[grp][dl] = a;
+    __syncthreads();
+    if (grp == 0 && d < D) {
+        const float s = dbd_acc[d];
+        dbd[d] = s;
+        dbpre[d] = s - (red[0][dl] + red[1][dl] + red[2][dl] + red[3][dl]);
+    }
+}
+
+template <typename T>
+static void launch_wgrad(int ept, dim3 grid, size_t sh, hipStream_t st, const float* vals, const int32_t* idx,
+                         const float* dpre, const T* xT, const T* gT, int B, int ldT, int H, int D, int K, int nsplit,
+                         int ntm, int ntn, float* out, int64_t slab_stride, float* dbe_slab) {
+#define WG_CASE(N)                                                                                                   \
+    if (ept <= N) {                                                                                                  \
+        wgrad_kernel<T, N><<<grid, 256, sh, st>>>(vals, idx, dpre, xT, gT, B, ldT, H, D, K, nsplit, ntm, ntn, out,   \
+                                                  slab_stride, dbe_slab);                                           \
+        return;                                                                                                      \
+    }
+    WG_CASE(1) WG_CASE(2) WG_CASE(4) WG_CASE(8) WG_CASE(16) WG_CASE(32)
+#undef WG_CASE
+}
+
 extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                                  const int32_t* rows, const float* vals, const int32_t* idx, const float* dpre,
                                  int32_t B, float* grads, void* stream) {
@@ -147,38 +210,44 @@ extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void*
     hipStream_t st = (hipStream_t)stream;
     const int D = ctx->D, H = ctx->H, K = ctx->K;
     const int ldT = (B + 127) / 128 * 128;
-    WSAE_PROF_BEGIN(ctx, WSAE_K_MEMSET, st);
-    WSAE_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)ctx->P * 4, st));
-    WSAE_PROF_END(ctx, WSAE_K_MEMSET, st);
-    float* dWe = grads + ctx->off[0];
-    float* dWdT = grads + ctx->off[1];
-    float* dbe = grads + ctx->off[2];
-    float* dbd = grads + ctx->off[3];
-    float* dbpre = grads + ctx->off[4];
-    const int tiles = ceil_div(H, TILE_M) * ceil_div(D, TILE_N) * 2;
     const int kt = ctx->prec == WSAE_PREC_BF16 ? 64 : 32;
     const int nchunks = ceil_div(B, kt);
-    int nsplit = max(1, min(nchunks, ceil_div(1024, tiles)));  // aim for ~4 workgroups per CU
-    if (nsplit > 1 && nchunks / nsplit < 8) nsplit = max(1, nchunks / 8);
-    dim3 grid(ceil_div(H, TILE_M), ceil_div(D, TILE_N), 2 * nsplit);
-    const size_t sh = 2 * TILE_LDS_BYTES + 128 * sizeof(float);
+    const int ntm = ceil_div(H, TILE_M), ntn = ceil_div(D, TILE_N);
+    const int nsplit = min(WSAE_WGRAD_MAX_SPLIT, max(1, nchunks / 4));  // >= 4 chunks per split; 8 = one per XCD
+    const int64_t slab_stride = 2 * (int64_t)H * D;
+    const int ept = ceil_div(kt * K, 256);
+    dim3 grid(ntm * ntn * 2 * nsplit);
+    const size_t sh = 2 * TILE_LDS_BYTES;
+    float* out = ctx->wg_slabs;
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD, st);
     if (ctx->prec == WSAE_PREC_BF16)
-        wgrad_kernel<bf16_t><<<grid, 256, sh, st>>>(vals, idx, dpre, (const bf16_t*)ctx->xT, (const bf16_t*)ctx->gT, B,
-                                                    ldT, H, D, K, nsplit, dWe, dWdT, dbe);
+        launch_wgrad<bf16_t>(ept, grid, sh, st, vals, idx, dpre, (const bf16_t*)ctx->xT, (const bf16_t*)ctx->gT, B, ldT,
+                             H, D, K, nsplit, ntm, ntn, out, slab_stride, ctx->dbe_slab);
     else
-        wgrad_kernel<float><<<grid, 256, sh, st>>>(vals, idx, dpre, (const float*)ctx->xT, (const float*)ctx->gT, B, ldT,
-                                                   H, D, K, nsplit, dWe, dWdT, dbe);
+        launch_wgrad<float>(ept, grid, sh, st, vals, idx, dpre, (const float*)ctx->xT, (const float*)ctx->gT, B, ldT, H,
+                            D, K, nsplit, ntm, ntn, out, slab_stride, ctx->dbe_slab);
     WSAE_PROF_END(ctx, WSAE_K_WGRAD, st);
     WSAE_LAUNCH_CHECK();
+
+    float* dbe = grads + ctx->off[2];
     const float* bpre = params + ctx->off[4];
+    const int nrb = (int)min((int64_t)2048, ceil_div64(slab_stride / 4, 256));
+    WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD_REDUCE, st);
+    if (ctx->prec == WSAE_PREC_BF16)
+        wgrad_reduce_kernel<true><<<nrb, 256, 0, st>>>(out, slab_stride, ctx->dbe_slab, nsplit, bpre, grads, dbe, H, D);
+    else
+        wgrad_reduce_kernel<false><<<nrb, 256, 0, st>>>(out, slab_stride, ctx->dbe_slab, nsplit, bpre, grads, dbe, H, D);
+    WSAE_PROF_END(ctx, WSAE_K_WGRAD_REDUCE, st);
+    WSAE_LAUNCH_CHECK();
+
+    const int nblk = ceil_div(H, 32);
     WSAE_PROF_BEGIN(ctx, WSAE_K_BIAS_GRADS, st);
     if (ctx->prec == WSAE_PREC_BF16)
-        bias_grads_kernel<bf16_t, true><<<ceil_div(H, 32), 256, 0, st>>>(ctx->We_bf16, bpre, ctx->part_dbd, dWe, dbe, dbd,
-                                                                        dbpre, H, D);
+        dbpre_partial_kernel<bf16_t><<<nblk, 256, 0, st>>>(ctx->We_bf16, dbe, ctx->dbpre_part, H, D);
     else
-        bias_grads_kernel<float, false><<<ceil_div(H, 32), 256, 0, st>>>(params + ctx->off[0], bpre, ctx->part_dbd, dWe,
-                                                                        dbe, dbd, dbpre, H, D);
+        dbpre_partial_kernel<float><<<nblk, 256, 0, st>>>(params + ctx->off[0], dbe, ctx->dbpre_part, H, D);
+    bias_finish_kernel<<<ceil_div(D, 64), 256, 0, st>>>(ctx->part_dbd, ctx->dbpre_part, nblk, grads + ctx->off[3],
+                                                        grads + ctx->off[4], D);
     WSAE_PROF_END(ctx, WSAE_K_BIAS_GRADS, st);
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;
