@@ -222,7 +222,8 @@ int wsae_ring_fill_synthetic(wsae_ring* ring, uint64_t seed, int64_t n_rows, voi
 #define WSAE_K_DEAD_SCAN 12
 #define WSAE_K_MEMSET 13
 #define WSAE_K_WGRAD_REDUCE 14
-#define WSAE_K_COUNT 15
+#define WSAE_K_BUCKET 15
+#define WSAE_K_COUNT 16
 const char* wsae_kernel_name(int32_t kernel_id);
 int wsae_profile_enable(wsae_ctx* ctx, int32_t kernel_id, int32_t max_samples);
 int wsae_profile_disable(wsae_ctx* ctx);

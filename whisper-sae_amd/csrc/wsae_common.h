@@ -84,6 +84,10 @@ struct wsae_ctx {
     float* wg_slabs;      // [WSAE_WGRAD_MAX_SPLIT][2*H*D] split-K partial weight gradients
     float* dbe_slab;      // [WSAE_WGRAD_MAX_SPLIT][H]
     float* dbpre_part;    // [ceil(H/32)][D]
+    uint32_t* ent_pos;    // [maxB*K] bucketed compact code: (feature & 127) << 16 | row-in-chunk
+    void* ent_hid;        // [maxB*K] relu(value) in the contraction dtype, bucket order
+    void* ent_dpre;       // [maxB*K] dpre, bucket order
+    int32_t* ent_off;     // [ceil(maxB/32)][ceil(H/128)+1] bucket boundaries
     int32_t* counters;    // small int scratch (fallback rows, dead count, resample cursors)
     int32_t* dead_list;   // [H] compacted dead feature indices (resample)
     int32_t* row_order;   // [maxB] rows sorted by error (resample)

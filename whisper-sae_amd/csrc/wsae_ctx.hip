@@ -84,6 +84,10 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     const size_t o_ws = cv.take((size_t)WSAE_WGRAD_MAX_SPLIT * 2 * H * D * 4);
     const size_t o_ds = cv.take((size_t)WSAE_WGRAD_MAX_SPLIT * H * 4);
     const size_t o_dp = cv.take((size_t)((H + 31) / 32) * D * 4);
+    const size_t o_ep = cv.take((size_t)maxB * K * 4);
+    const size_t o_eh = cv.take((size_t)maxB * K * 4);
+    const size_t o_ed = cv.take((size_t)maxB * K * 4);
+    const size_t o_eo = cv.take((size_t)((maxB + 31) / 32) * ((H + 127) / 128 + 1) * 4);
     const size_t o_dl = cv.take((size_t)H * 4);
     const size_t o_ro = cv.take((size_t)maxB * 4);
     char* base = nullptr;
@@ -116,6 +120,10 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     c->wg_slabs = (float*)(base + o_ws);
     c->dbe_slab = (float*)(base + o_ds);
     c->dbpre_part = (float*)(base + o_dp);
+    c->ent_pos = (uint32_t*)(base + o_ep);
+    c->ent_hid = base + o_eh;
+    c->ent_dpre = base + o_ed;
+    c->ent_off = (int32_t*)(base + o_eo);
     c->dead_list = (int32_t*)(base + o_dl);
     c->row_order = (int32_t*)(base + o_ro);
     c->ws_bytes = cv.total;
@@ -134,7 +142,7 @@ extern "C" int wsae_ctx_destroy(wsae_ctx* ctx) {
 // ---- kernel timing -------------------------------------------------------------------------------
 static const char* const k_names[WSAE_K_COUNT] = {
     "stage_batch", "encode_gemm", "topk", "decode", "decode_finalize", "transpose_g", "wgrad",
-    "bias_grads", "sqnorm", "adamw", "rownorm", "prepare", "dead_scan", "memset", "wgrad_reduce"};
+    "bias_grads", "sqnorm", "adamw", "rownorm", "prepare", "dead_scan", "memset", "wgrad_reduce", "bucket"};
 
 extern "C" const char* wsae_kernel_name(int32_t id) { return (id >= 0 && id < WSAE_K_COUNT) ? k_names[id] : "?"; }
 

@@ -20,24 +20,87 @@
 #include "wsae_common.h"
 #include "wsae_mfma.h"
 
-template <typename T, int EPT>
+// ------------------------------------------------------------------------------------------------
+// bucket_kernel: per KT-row chunk, counting-sort the chunk's KT*K compact entries by 128-feature tile.
+//   ent_off[chunk][t] .. ent_off[chunk][t+1] : positions (in the flat sorted arrays) of the entries of
+//   tile t;  ent_pos = (feature & 127) << 16 | row-in-chunk;  ent_hid = relu(value), ent_dpre = dpre.
+// A (tile, chunk) workgroup of the contraction then touches only its own ~KT*K*128/H entries
+// instead of scanning all KT*K of them for a 128/H hit rate.
+// ------------------------------------------------------------------------------------------------
+#define BUCKET_MAX_TILES 512
+
+template <typename T>
 __global__ void __launch_bounds__(256)
-wgrad_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, const float* __restrict__ dpre,
-             const T* __restrict__ xT, const T* __restrict__ gT, int B, int ldT, int H, int D, int K, int nsplit,
-             int ntm, int ntn, float* __restrict__ out, int64_t slab_stride, float* __restrict__ dbe_slab) {
+bucket_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, const float* __restrict__ dpre, int B,
+              int K, int ntiles, uint32_t* __restrict__ ent_pos, T* __restrict__ ent_hid, T* __restrict__ ent_dpre,
+              int32_t* __restrict__ ent_off) {
+    __shared__ int cnt[BUCKET_MAX_TILES];
+    __shared__ int cur[BUCKET_MAX_TILES];
+    constexpr int KT = Mfma<T>::KT;
+    const int chunk = blockIdx.x, tid = threadIdx.x;
+    const int b0 = chunk * KT;
+    const int nent = min(KT, B - b0) * K;
+    const int64_t base = (int64_t)b0 * K;
+    for (int t = tid; t < ntiles; t += 256) cnt[t] = 0;
+    __syncthreads();
+    for (int e = tid; e < nent; e += 256) atomicAdd(&cnt[idx[base + e] >> 7], 1);
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan over tiles by one wave
+        int carry = 0;
+        for (int t0 = 0; t0 < ntiles; t0 += 64) {
+            const int t = t0 + tid;
+            const int c = t < ntiles ? cnt[t] : 0;
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int n = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += n;
+            }
+            if (t < ntiles) {
+                cur[t] = carry + incl - c;
+                ent_off[(int64_t)chunk * (ntiles + 1) + t] = (int)base + carry + incl - c;
+            }
+            carry += __shfl(incl, 63, 64);
+        }
+        if (tid == 0) ent_off[(int64_t)chunk * (ntiles + 1) + ntiles] = (int)base + carry;
+    }
+    __syncthreads();
+    for (int e = tid; e < nent; e += 256) {
+        const int f = idx[base + e];
+        const int p = atomicAdd(&cur[f >> 7], 1);
+        const float v = vals[base + e];
+        ent_pos[base + p] = ((uint32_t)(f & 127) << 16) | (uint32_t)(e / K);
+        ent_hid[base + p] = (T)(v > 0.f ? v : 0.f);
+        ent_dpre[base + p] = (T)dpre[base + e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad_kernel: one 128-feature x 128-column tile of dW_dT (which = 0) or dW_e (which = 1) over one
+// batch split.  Per KT-row chunk: zero the sparse slice A[buf], scatter the tile's bucketed entries
+// into it, stage the dense slab Bt[buf], MFMA.  A and Bt are double-buffered so that two barriers
+// per chunk suffice: zero(k) may start as soon as every wave has passed the second barrier of chunk
+// k-1 (all reads of buffer k&1 belong to chunk k-2), and the operands of chunk k+1 are fetched into
+// registers while the MFMAs of chunk k run.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid, const T* __restrict__ ent_dpre,
+             const int32_t* __restrict__ ent_off, const T* __restrict__ xT, const T* __restrict__ gT, int B, int ldT,
+             int H, int D, int nsplit, int ntm, int ntn, float* __restrict__ out, int64_t slab_stride,
+             float* __restrict__ dbe_slab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;
-    char* Bs = smem + TILE_LDS_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int split = blockIdx.x % nsplit;
     int tile = blockIdx.x / nsplit;
     const int which = tile / (ntm * ntn);  // 0: dW_dT (hidden, g)   1: dW_e (dpre, x_c)
     tile -= which * ntm * ntn;
-    const int f0 = (tile / ntn) * TILE_M, d0 = (tile % ntn) * TILE_N;
+    const int tm = tile / ntn;
+    const int f0 = tm * TILE_M, d0 = (tile % ntn) * TILE_N;
     constexpr int KT = Mfma<T>::KT;
     const T* Bt = which == 0 ? gT : xT;
-    const float* sv = which == 0 ? vals : dpre;
+    const T* sv = which == 0 ? ent_hid : ent_dpre;
     const bool do_dbe = (which == 1) && (d0 == 0);
 
     const int nchunks = (B + KT - 1) / KT;
@@ -54,44 +117,34 @@ wgrad_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, co
     float dbe_acc = 0.f;  // thread t < 128 owns feature row f0 + t
 
     SlabRegs<T> rb;
-    int ef[EPT];
-    float ev[EPT];
-    auto load_entries = [&](int ck) {
-        const int b0 = ck * KT;
-        const int nent = min(KT, B - b0) * K;
-        const int64_t base = (int64_t)b0 * K;
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int e = tid + 256 * i;
-            const bool ok = e < nent;
-            ef[i] = ok ? idx[base + e] - f0 : -1;
-            ev[i] = ok ? sv[base + e] : 0.f;
+    int e_lo = 0, e_n = 0;   // entry range of the chunk whose operands sit in registers
+    uint32_t e_pos = 0;      // first 256 entries: one per thread
+    T e_val = (T)0.f;
+    auto fetch = [&](int ck) {
+        slab_load<T>(rb, Bt, ldT, d0, D, ck * KT, ldT, tid);
+        const int32_t* o = ent_off + (int64_t)ck * (ntm + 1) + tm;
+        e_lo = o[0];
+        e_n = o[1] - e_lo;
+        if (tid < e_n) {
+            e_pos = ent_pos[e_lo + tid];
+            e_val = sv[e_lo + tid];
         }
     };
-    if (c_begin < c_end) {
-        slab_load<T>(rb, Bt, ldT, d0, D, c_begin * KT, ldT, tid);
-        load_entries(c_begin);
-    }
+    if (c_begin < c_end) fetch(c_begin);
     for (int ck = c_begin; ck < c_end; ++ck) {
-        // zero the sparse slice, stage the dense one
+        const int buf = (ck - c_begin) & 1;
+        char* As = smem + buf * 2 * TILE_LDS_BYTES;
+        char* Bs = As + TILE_LDS_BYTES;
         for (int c = tid; c < TILE_LDS_BYTES / 16; c += 256) *(uint4*)(As + c * 16) = make_uint4(0, 0, 0, 0);
         slab_store<T>(rb, Bs, tid);
         __syncthreads();
-        // scatter the prefetched compact entries of rows [b0, b0+KT) whose feature lies in [f0, f0+128)
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int f = ef[i];
-            if ((unsigned)f < 128u) {
-                float v = ev[i];
-                if (which == 0) v = v > 0.f ? v : 0.f;  // hidden = relu(topk value)
-                const int bl = (tid + 256 * i) / K;
-                if (v != 0.f) *(T*)(As + f * LDS_ROW_BYTES + bl * (int)sizeof(T)) = (T)v;
-            }
+        const int n = e_n, lo = e_lo;
+        if (tid < n) *(T*)(As + (e_pos >> 16) * LDS_ROW_BYTES + (e_pos & 0xFFFFu) * (int)sizeof(T)) = e_val;
+        for (int e = tid + 256; e < n; e += 256) {  // buckets beyond 256 entries (rare)
+            const uint32_t p = ent_pos[lo + e];
+            *(T*)(As + (p >> 16) * LDS_ROW_BYTES + (p & 0xFFFFu) * (int)sizeof(T)) = sv[lo + e];
         }
-        if (ck + 1 < c_end) {  // next chunk's operands fly during the MFMAs
-            slab_load<T>(rb, Bt, ldT, d0, D, (ck + 1) * KT, ldT, tid);
-            load_entries(ck + 1);
-        }
+        if (ck + 1 < c_end) fetch(ck + 1);  // next chunk's operands fly during the MFMAs
         __syncthreads();
         if (do_dbe && tid < 128) {  // db_e: row sums of the slice, fixed order
             const T* row = (const T*)(As + tid * LDS_ROW_BYTES);
@@ -101,7 +154,6 @@ wgrad_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, co
             dbe_acc += s;
         }
         Mfma<T>::slab(As, Bs, wm * 64, wn * 64, lane, acc);
-        __syncthreads();
     }
 
     float* dst = out + (int64_t)split * slab_stride + (which == 0 ? (int64_t)H * D : 0);
@@ -188,17 +240,20 @@ __global__ void __launch_bounds__(256) bias_finish_kernel(const float* __restric
 }
 
 template <typename T>
-static void launch_wgrad(int ept, dim3 grid, size_t sh, hipStream_t st, const float* vals, const int32_t* idx,
-                         const float* dpre, const T* xT, const T* gT, int B, int ldT, int H, int D, int K, int nsplit,
-                         int ntm, int ntn, float* out, int64_t slab_stride, float* dbe_slab) {
-#define WG_CASE(N)                                                                                                   \
-    if (ept <= N) {                                                                                                  \
-        wgrad_kernel<T, N><<<grid, 256, sh, st>>>(vals, idx, dpre, xT, gT, B, ldT, H, D, K, nsplit, ntm, ntn, out,   \
-                                                  slab_stride, dbe_slab);                                           \
-        return;                                                                                                      \
-    }
-    WG_CASE(1) WG_CASE(2) WG_CASE(4) WG_CASE(8) WG_CASE(16) WG_CASE(32)
-#undef WG_CASE
+static void launch_wgrad(wsae_ctx* ctx, dim3 grid, size_t sh, hipStream_t st, const float* vals, const int32_t* idx,
+                         const float* dpre, int B, int ldT, int nsplit, int ntm, int ntn, float* out,
+                         int64_t slab_stride) {
+    constexpr int KT = Mfma<T>::KT;
+    const int nchunks = ceil_div(B, KT);
+    WSAE_PROF_BEGIN(ctx, WSAE_K_BUCKET, st);
+    bucket_kernel<T><<<nchunks, 256, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, ctx->ent_pos, (T*)ctx->ent_hid,
+                                              (T*)ctx->ent_dpre, ctx->ent_off);
+    WSAE_PROF_END(ctx, WSAE_K_BUCKET, st);
+    WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD, st);
+    wgrad_kernel<T><<<grid, 256, sh, st>>>(ctx->ent_pos, (const T*)ctx->ent_hid, (const T*)ctx->ent_dpre, ctx->ent_off,
+                                           (const T*)ctx->xT, (const T*)ctx->gT, B, ldT, ctx->H, ctx->D, nsplit, ntm, ntn,
+                                           out, slab_stride, ctx->dbe_slab);
+    WSAE_PROF_END(ctx, WSAE_K_WGRAD, st);
 }
 
 extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
@@ -208,25 +263,21 @@ extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void*
     WSAE_REQUIRE(ctx && params && vals && idx && dpre && grads, "wsae_weight_grads: null argument");
     WSAE_REQUIRE(B >= 1 && B <= ctx->maxB, "wsae_weight_grads: batch %d outside [1, %d]", B, ctx->maxB);
     hipStream_t st = (hipStream_t)stream;
-    const int D = ctx->D, H = ctx->H, K = ctx->K;
+    const int D = ctx->D, H = ctx->H;
     const int ldT = (B + 127) / 128 * 128;
     const int kt = ctx->prec == WSAE_PREC_BF16 ? 64 : 32;
     const int nchunks = ceil_div(B, kt);
     const int ntm = ceil_div(H, TILE_M), ntn = ceil_div(D, TILE_N);
     const int nsplit = min(WSAE_WGRAD_MAX_SPLIT, max(1, nchunks / 4));  // >= 4 chunks per split; 8 = one per XCD
     const int64_t slab_stride = 2 * (int64_t)H * D;
-    const int ept = ceil_div(kt * K, 256);
+    WSAE_REQUIRE(ntm <= BUCKET_MAX_TILES, "hidden_dim %d too large for the bucket pass (max %d)", H, BUCKET_MAX_TILES * 128);
     dim3 grid(ntm * ntn * 2 * nsplit);
-    const size_t sh = 2 * TILE_LDS_BYTES;
+    const size_t sh = 4 * TILE_LDS_BYTES;
     float* out = ctx->wg_slabs;
-    WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD, st);
     if (ctx->prec == WSAE_PREC_BF16)
-        launch_wgrad<bf16_t>(ept, grid, sh, st, vals, idx, dpre, (const bf16_t*)ctx->xT, (const bf16_t*)ctx->gT, B, ldT,
-                             H, D, K, nsplit, ntm, ntn, out, slab_stride, ctx->dbe_slab);
+        launch_wgrad<bf16_t>(ctx, grid, sh, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride);
     else
-        launch_wgrad<float>(ept, grid, sh, st, vals, idx, dpre, (const float*)ctx->xT, (const float*)ctx->gT, B, ldT, H,
-                            D, K, nsplit, ntm, ntn, out, slab_stride, ctx->dbe_slab);
-    WSAE_PROF_END(ctx, WSAE_K_WGRAD, st);
+        launch_wgrad<float>(ctx, grid, sh, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride);
     WSAE_LAUNCH_CHECK();
 
     float* dbe = grads + ctx->off[2];

@@ -143,7 +143,7 @@ def pack_layout(input_dim: int, hidden_dim: int) -> tuple:
     return 2 * d * h + h + 2 * d, off
 
 
-KERNEL_COUNT = 15
+KERNEL_COUNT = 16
 
 
 def profile_read(handle: int) -> dict:
