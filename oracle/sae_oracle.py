@@ -22,8 +22,9 @@ Two arithmetic modes, matching the two modes of the HIP path:
 * ``"fp32"`` -- the reference CPU semantics: everything in float32 (intermediates here are
   float64 and rounded at the points where the reference stores a float32 tensor).
 * ``"amp"`` -- what the MI355X path computes under ``use_amp`` (bf16 MFMA operands, fp32
-  accumulate): ``pre = bf16(W_e) @ bf16(x) + (b_e - bf16(W_e) @ b_pre)``; decode, residual, loss and
-  ``dh`` in fp32; weight gradients from bf16-rounded ``hidden``, ``g``, ``dpre``, ``x``.  On inputs
+  accumulate): ``pre = bf16(W_e) @ bf16(x) + (b_e - bf16(W_e) @ b_pre)``; decode and ``dh`` gather rows
+  of the bf16 shadow of ``W_d`` and accumulate in fp32 (TopK values, residual, loss, ``g`` stay
+  fp32); weight gradients from bf16-rounded ``hidden``, ``g``, ``dpre``, ``x``.  On inputs
   whose ``x``/``W_e`` are bf16-representable the two modes agree in the forward pass to fp32
   rounding, which is how "identical inputs" parity with the reference is defined.
 
@@ -134,9 +135,10 @@ def densify(vals: np.ndarray, idx: np.ndarray, hidden_dim: int) -> np.ndarray:
     return hidden
 
 
-def decode(st: SAEState, hidden: np.ndarray) -> np.ndarray:
-    """model.py:129: ``decoder(hidden) + b_pre``."""
-    return (hidden.astype(F64) @ st.W_d.astype(F64).T + st.b_d.astype(F64)
+def decode(st: SAEState, hidden: np.ndarray, mode: str = "fp32") -> np.ndarray:
+    """model.py:129: ``decoder(hidden) + b_pre`` (``"amp"``: through the bf16 shadow of W_d)."""
+    w_d = bf16_round(st.W_d) if mode == "amp" else st.W_d
+    return (hidden.astype(F64) @ w_d.astype(F64).T + st.b_d.astype(F64)
             + st.b_pre.astype(F64)).astype(F32)
 
 
@@ -146,7 +148,7 @@ def forward(st: SAEState, x: np.ndarray, mode: str = "fp32", training: bool = Tr
     pre = pre_activation(st, x, mode)
     vals, idx = topk_select(pre, st.k)
     hidden = densify(vals, idx, st.W_e.shape[0])
-    recon = decode(st, hidden)
+    recon = decode(st, hidden, mode)
     resid = recon.astype(F64) - x.astype(F64)
     loss = F32(np.mean(resid * resid))  # F.mse_loss, mean over B*D (model.py:145)
     l0 = F32((hidden > 0).sum(axis=1).astype(F64).mean())  # model.py:148
@@ -192,7 +194,8 @@ def backward(st: SAEState, x: np.ndarray, fwd: dict, mode: str = "fp32") -> dict
     g = (2.0 * (fwd["reconstructed"].astype(F64) - x.astype(F64)) / (B * D)).astype(F32)
     g64 = g.astype(F64)
     db_d = g64.sum(axis=0)
-    dh = g64 @ st.W_d.astype(F64)  # [B, H]
+    w_d = bf16_round(st.W_d) if mode == "amp" else st.W_d  # the decoder weights the forward used
+    dh = g64 @ w_d.astype(F64)  # [B, H]
     dpre = np.where(hidden > 0, dh, 0.0)
     if mode == "fp32":
         xc = (x - st.b_pre).astype(F64)

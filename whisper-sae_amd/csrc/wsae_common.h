@@ -69,6 +69,7 @@ struct wsae_ctx {
     int64_t off[5];       // W_e, W_dT, b_e, b_d, b_pre
     // ---- derived shadows -------------------------------------------------------------------
     bf16_t* We_bf16;      // [H][D]  (BF16 mode)
+    bf16_t* WdT_bf16;     // [H][D]  bf16 shadow of W_dT (BF16 mode: decode / dpre gathers)
     float* c_fold;        // [H] folded encoder bias (BF16 mode)
     // ---- per-batch workspace ---------------------------------------------------------------
     void* xb;             // [maxB][D] staged batch in compute dtype (bf16 | f32 = x - b_pre)

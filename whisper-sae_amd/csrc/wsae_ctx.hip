@@ -69,6 +69,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     const size_t maxBp = ((size_t)maxB + 127) / 128 * 128;  // transposed operands are padded to 128 columns
     Carver cv;
     const size_t o_we = cv.take((size_t)H * D * 2);
+    const size_t o_wd = cv.take((size_t)H * D * 2);
     const size_t o_cf = cv.take((size_t)H * 4);
     const size_t o_xb = cv.take((size_t)maxB * D * esz);
     const size_t o_xT = cv.take(maxBp * D * esz);
@@ -105,6 +106,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
         return WSAE_ERR_HIP;
     }
     c->We_bf16 = (bf16_t*)(base + o_we);
+    c->WdT_bf16 = (bf16_t*)(base + o_wd);
     c->c_fold = (float*)(base + o_cf);
     c->xb = base + o_xb;
     c->xT = base + o_xT;
@@ -208,16 +210,22 @@ extern "C" size_t wsae_ctx_workspace_bytes(const wsae_ctx* ctx) { return ctx ? c
 // wsae_prepare: bf16 shadow of W_e + folded bias.  One wave per feature row.
 //   c[h] = b_e[h] - sum_d bf16(W_e[h,d]) * b_pre[d]      (oracle: pre_activation, mode "amp")
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) prepare_kernel(const float* __restrict__ We, const float* __restrict__ be,
-                                                      const float* __restrict__ bpre, bf16_t* __restrict__ We16,
+__global__ void __launch_bounds__(256) prepare_kernel(const float* __restrict__ We, const float* __restrict__ WdT,
+                                                      const float* __restrict__ be, const float* __restrict__ bpre,
+                                                      bf16_t* __restrict__ We16, bf16_t* __restrict__ WdT16,
                                                       float* __restrict__ cfold, int H, int D) {
     const int lane = threadIdx.x & 63;
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= H) return;
     const float* row = We + (int64_t)h * D;
     bf16_t* orow = We16 + (int64_t)h * D;
+    const float* drow = WdT + (int64_t)h * D;
+    bf16_t* odrow = WdT16 + (int64_t)h * D;
     float dot = 0.f;
     for (int d = lane * 2; d < D; d += 128) {
+        const float2 wd = *(const float2*)(drow + d);
+        odrow[d] = (bf16_t)wd.x;
+        odrow[d + 1] = (bf16_t)wd.y;
         const float2 w = *(const float2*)(row + d);
         const bf16_t w0 = (bf16_t)w.x, w1 = (bf16_t)w.y;
         orow[d] = w0;
@@ -232,9 +240,9 @@ __global__ void __launch_bounds__(256) prepare_kernel(const float* __restrict__ 
 int wsae_prepare_launch(wsae_ctx* ctx, const float* params, hipStream_t st) {
     if (ctx->prec != WSAE_PREC_BF16) return WSAE_OK;
     WSAE_PROF_BEGIN(ctx, WSAE_K_PREPARE, st);
-    prepare_kernel<<<ceil_div(ctx->H, 4), 256, 0, st>>>(params + ctx->off[0], params + ctx->off[2],
-                                                        params + ctx->off[4], ctx->We_bf16, ctx->c_fold,
-                                                        ctx->H, ctx->D);
+    prepare_kernel<<<ceil_div(ctx->H, 4), 256, 0, st>>>(params + ctx->off[0], params + ctx->off[1],
+                                                        params + ctx->off[2], params + ctx->off[4], ctx->We_bf16,
+                                                        ctx->WdT_bf16, ctx->c_fold, ctx->H, ctx->D);
     WSAE_PROF_END(ctx, WSAE_K_PREPARE, st);
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;

@@ -6,9 +6,9 @@
 // k gathers per row are coalesced; lane l owns elements l, l+64, ... of the row.
 #include "wsae_common.h"
 
-template <int EPL, int XDT, bool BWD, bool ROUND_DPRE>
+template <typename TW, int EPL, int XDT, bool BWD, bool ROUND_DPRE>
 __global__ void __launch_bounds__(256)
-decode_kernel(const float* __restrict__ WdT, const float* __restrict__ bd, const float* __restrict__ bpre,
+decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const float* __restrict__ bpre,
               const void* __restrict__ x, const int32_t* __restrict__ rows, const float* __restrict__ vals,
               const int32_t* __restrict__ idx, int B, int D, int K, float* __restrict__ recon_out,
               float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated,
@@ -48,11 +48,11 @@ decode_kernel(const float* __restrict__ WdT, const float* __restrict__ bd, const
                 const float vj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j));
                 if (!(vj > 0.f)) continue;
                 const int fj = __builtin_amdgcn_readlane(f, j);
-                const float* w = WdT + (int64_t)fj * D;
+                const TW* w = WdT + (int64_t)fj * D;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     const int d = lane + 64 * e;
-                    if (d < D) rec[e] = fmaf(vj, w[d], rec[e]);
+                    if (d < D) rec[e] = fmaf(vj, (float)w[d], rec[e]);
                 }
             }
         }
@@ -84,12 +84,12 @@ decode_kernel(const float* __restrict__ WdT, const float* __restrict__ bd, const
                     const float vj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j));
                     if (!(vj > 0.f)) continue;
                     const int fj = __builtin_amdgcn_readlane(f, j);
-                    const float* w = WdT + (int64_t)fj * D;
+                    const TW* w = WdT + (int64_t)fj * D;
                     float dot = 0.f;
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) {
                         const int d = lane + 64 * e;
-                        if (d < D) dot = fmaf(g[e], w[d], dot);
+                        if (d < D) dot = fmaf(g[e], (float)w[d], dot);
                     }
                     dot = wave_sum(dot);
                     if (lane == j) mine = dot;
@@ -114,6 +114,179 @@ decode_kernel(const float* __restrict__ WdT, const float* __restrict__ bd, const
         }
         __syncthreads();
         // sum_b g joins the [D] accumulator at the head of part_dbd (zeroed by the launcher)
+        for (int d = threadIdx.x; d < D; d += 256)
+            atomicAdd(part_dbd + d, dbd_s[d] + dbd_s[D + d] + dbd_s[2 * D + d] + dbd_s[3 * D + d]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path (K even <= 64, D = 32*EPL): still one wave per batch row, but
+//   * the two 32-lane halves of the wave work on two different selected features at once; lane li
+//     of a half owns the EPL contiguous elements [EPL*li, EPL*(li+1)) of a decoder row, fetched as
+//     8/16-byte loads (a whole 768-byte bf16 row of W_dT per half-wave instruction group);
+//   * the K gathered rows stay in registers (packed bf16) between the decode pass and the dpre
+//     pass, so every W_dT row is read once per (batch row, selected feature);
+//   * the K/2 per-half dot products are reduced with a transposing butterfly (15 shuffles for 16
+//     values instead of 16 x 5).
+// W_dT is the bf16 shadow in BF16 mode (2.36 MB at cfg2: resident in every XCD's 4 MB L2) and the
+// fp32 master in FP32 mode.
+// ------------------------------------------------------------------------------------------------
+template <typename TW, int EPL>
+struct RowSeg {
+    static constexpr int NB = EPL * (int)sizeof(TW);                       // bytes per lane
+    static constexpr int CS = (NB % 16 == 0) ? 16 : (NB % 8 == 0) ? 8 : 4;  // load width
+    static constexpr int NW = NB / 4;                                       // dwords per lane
+    uint32_t w[NW];
+    __device__ __forceinline__ void load(const TW* row, int li) {
+        const char* p = (const char*)row + NB * li;
+#pragma unroll
+        for (int o = 0; o < NB; o += CS) {
+            if (CS == 16) {
+                const uint4 v = *(const uint4*)(p + o);
+                w[o / 4] = v.x; w[o / 4 + 1] = v.y; w[o / 4 + 2] = v.z; w[o / 4 + 3] = v.w;
+            } else if (CS == 8) {
+                const uint2 v = *(const uint2*)(p + o);
+                w[o / 4] = v.x; w[o / 4 + 1] = v.y;
+            } else {
+                w[o / 4] = *(const uint32_t*)(p + o);
+            }
+        }
+    }
+    __device__ __forceinline__ float get(int e) const {
+        if (sizeof(TW) == 4) return __uint_as_float(w[e]);
+        const uint32_t u = w[e >> 1];
+        return __uint_as_float((e & 1) ? (u & 0xFFFF0000u) : (u << 16));
+    }
+};
+
+template <int KJ, int N, int M>
+__device__ __forceinline__ void bfly(float (&pd)[KJ], int li) {
+    if constexpr (M >= 1) {
+        if constexpr (N >= 1) {
+            const bool up = (li & M) != 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float send = up ? pd[i] : pd[i + N];
+                const float keep = up ? pd[i + N] : pd[i];
+                pd[i] = keep + __shfl_xor(send, M, 64);
+            }
+            bfly<KJ, N / 2, M / 2>(pd, li);
+        } else {
+            pd[0] += __shfl_xor(pd[0], M, 64);
+            bfly<KJ, 0, M / 2>(pd, li);
+        }
+    }
+}
+
+template <typename TW, int EPL, int KJ, int XDT, bool BWD, bool ROUND_DPRE>
+__global__ void __launch_bounds__(256, 2)
+decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const float* __restrict__ bpre,
+                   const void* __restrict__ x, const int32_t* __restrict__ rows, const float* __restrict__ vals,
+                   const int32_t* __restrict__ idx, int B, int K, float* __restrict__ recon_out,
+                   float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated,
+                   const int64_t* __restrict__ step_count, float* __restrict__ part_loss,
+                   float* __restrict__ part_l0, float* __restrict__ part_dbd) {
+    constexpr int D = 32 * EPL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)smem;        // [8]
+    float* dbd_s = (float*)smem + 8;  // [4][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, li = lane & 31;
+    const float scale = 2.0f / ((float)B * (float)D);
+    const int64_t step = (last_activated && step_count) ? *step_count : 0;
+
+    float bsum[EPL], dbd[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        bsum[e] = bd[EPL * li + e] + bpre[EPL * li + e];
+        dbd[e] = 0.f;
+    }
+    float loss_acc = 0.f;
+    int l0_acc = 0;
+
+    for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+        const int64_t code = (int64_t)b * K;
+        const float v_l = (lane < K) ? vals[code + lane] : 0.f;
+        const int f_l = (lane < K) ? idx[code + lane] : 0;
+        const bool on = v_l > 0.f;
+        l0_acc += __popcll(__ballot(on));
+        if (on && last_activated) last_activated[f_l] = step;  // model.py:178-181
+        const float vr_l = on ? v_l : 0.f;
+
+        RowSeg<TW, EPL> seg[KJ];
+        float acc[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+        // ---- decode: this half accumulates features j = 2*jj + half ----
+#pragma unroll
+        for (int jj = 0; jj < KJ; ++jj) {
+            const int j = 2 * jj + half;
+            const float vj = __shfl(vr_l, j, 64);
+            const int fj = __shfl(f_l, j, 64);  // lanes >= K carry feature 0, value 0
+            seg[jj].load(WdT + (int64_t)fj * D, li);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(vj, seg[jj].get(e), acc[e]);
+        }
+        // ---- residual, loss, g (both halves end up with the full sum) ----
+        const int64_t src = rows ? (int64_t)rows[b] : (int64_t)b;
+        float g[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float rec = acc[e] + __shfl_xor(acc[e], 32, 64) + bsum[e];
+            const float xv = load_act<XDT>(x, src * D + EPL * li + e);
+            const float r = rec - xv;
+            g[e] = r * scale;
+            if (half == 0) {
+                loss_acc = fmaf(r, r, loss_acc);
+                dbd[e] += g[e];
+                if (recon_out) recon_out[(int64_t)b * D + EPL * li + e] = rec;
+                if (BWD) g_out[(int64_t)b * D + EPL * li + e] = g[e];
+            }
+        }
+        // ---- dpre_j = (v_j > 0) ? g . W_dT[idx_j, :] : 0 ----
+        if (BWD) {
+            float pd[KJ];
+#pragma unroll
+            for (int jj = 0; jj < KJ; ++jj) {
+                // keep the rows PACKED across the two passes: without this the compiler carries the
+                // 16 x 12 unpacked floats of the decode pass over (354 registers, 1 wave per SIMD)
+#pragma unroll
+                for (int q = 0; q < RowSeg<TW, EPL>::NW; ++q) asm volatile("" : "+v"(seg[jj].w[q]));
+                float dot = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dot = fmaf(g[e], seg[jj].get(e), dot);
+                pd[jj] = dot;
+            }
+            // transposing butterfly over the 32 lanes of each half: a stage with lane mask m halves
+            // the number of live values (lanes with the bit set keep the upper half); once one value
+            // is left the remaining masks are a plain all-reduce.  Lane li ends up with the total of
+            // jj = top log2(KJ) bits of li.
+            bfly<KJ, KJ / 2, 16>(pd, li);
+            // which jj does this lane hold?  the selection bits came from li's top log2(KJ) bits
+            int sh = 0;
+#pragma unroll
+            for (int t = KJ; t > 1; t >>= 1) ++sh;
+            const int jj_mine = (li >> (5 - sh)) & (KJ - 1);
+            const int j_mine = 2 * jj_mine + half;
+            const float vj = __shfl(v_l, j_mine, 64);
+            float out = vj > 0.f ? pd[0] : 0.f;
+            if (ROUND_DPRE) out = (float)(bf16_t)out;
+            const bool writer = (li & ((32 >> sh) - 1)) == 0 && j_mine < K;
+            if (writer) dpre[code + j_mine] = out;
+        }
+    }
+
+    const float bl = block_sum(loss_acc, red);
+    if (threadIdx.x == 0) part_loss[blockIdx.x] = bl;
+    const float b0 = block_sum(lane == 0 ? (float)l0_acc : 0.f, red);
+    if (threadIdx.x == 0) part_l0[blockIdx.x] = b0;
+    if (BWD) {
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dbd_s[wave * D + EPL * li + e] = dbd[e];
+        }
+        __syncthreads();
         for (int d = threadIdx.x; d < D; d += 256)
             atomicAdd(part_dbd + d, dbd_s[d] + dbd_s[D + d] + dbd_s[2 * D + d] + dbd_s[3 * D + d]);
     }
@@ -155,40 +328,79 @@ __global__ void __launch_bounds__(256) transpose_g_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int EPL, int XDT>
-static void launch_decode(wsae_ctx* c, const float* params, const void* x, const int32_t* rows, const float* vals,
-                          const int32_t* idx, int B, float* recon, int want_bwd, float* dpre, int64_t* last_activated,
-                          const int64_t* step_count, int nblk, hipStream_t st) {
-    const float* WdT = params + c->off[1];
+template <typename TW, int EPL, int XDT>
+static void launch_decode(wsae_ctx* c, const TW* WdT, const float* params, const void* x, const int32_t* rows,
+                          const float* vals, const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
+                          int64_t* last_activated, const int64_t* step_count, int nblk, hipStream_t st) {
     const float* bd = params + c->off[3];
     const float* bpre = params + c->off[4];
     const size_t sh = (8 + 4 * (size_t)c->D) * sizeof(float);
 #define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->D, c->K, recon, dpre, c->g, last_activated, step_count, \
                  c->part_loss, c->part_l0, c->part_dbd
     if (!want_bwd)
-        decode_kernel<EPL, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
+        decode_kernel<TW, EPL, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
     else if (c->prec == WSAE_PREC_BF16)
-        decode_kernel<EPL, XDT, true, true><<<nblk, 256, sh, st>>>(DEC_ARGS);
+        decode_kernel<TW, EPL, XDT, true, true><<<nblk, 256, sh, st>>>(DEC_ARGS);
     else
-        decode_kernel<EPL, XDT, true, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
+        decode_kernel<TW, EPL, XDT, true, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
 #undef DEC_ARGS
 }
 
-template <int XDT>
-static int dispatch_decode(wsae_ctx* c, const float* params, const void* x, const int32_t* rows, const float* vals,
-                           const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
+template <typename TW, int EPL, int KJ, int XDT>
+static void launch_decode_fast(wsae_ctx* c, const TW* WdT, const float* params, const void* x, const int32_t* rows,
+                               const float* vals, const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
+                               int64_t* last_activated, const int64_t* step_count, int nblk, hipStream_t st) {
+    const float* bd = params + c->off[3];
+    const float* bpre = params + c->off[4];
+    const size_t sh = (8 + 4 * (size_t)c->D) * sizeof(float);
+#define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->K, recon, dpre, c->g, last_activated, step_count, \
+                 c->part_loss, c->part_l0, c->part_dbd
+    if (!want_bwd)
+        decode_fast_kernel<TW, EPL, KJ, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
+    else if (c->prec == WSAE_PREC_BF16)
+        decode_fast_kernel<TW, EPL, KJ, XDT, true, true><<<nblk, 256, sh, st>>>(DEC_ARGS);
+    else
+        decode_fast_kernel<TW, EPL, KJ, XDT, true, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
+#undef DEC_ARGS
+}
+
+template <typename TW, int XDT>
+static int dispatch_decode(wsae_ctx* c, const TW* WdT, const float* params, const void* x, const int32_t* rows,
+                           const float* vals, const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
                            int64_t* last_activated, const int64_t* step_count, int nblk, hipStream_t st) {
+    // fast path: (D = 32*EPL, K = 2*KJ) shapes with the gathered rows held in registers
+#define FAST_CASE(E, J)                                                                                            \
+    if (c->D == 32 * E && c->K == 2 * J) {                                                                         \
+        launch_decode_fast<TW, E, J, XDT>(c, WdT, params, x, rows, vals, idx, B, recon, want_bwd, dpre,            \
+                                          last_activated, step_count, nblk, st);                                   \
+        return WSAE_OK;                                                                                            \
+    }
+    FAST_CASE(12, 16)  // 384, k = 32 (whisper-tiny, cfg 1-3)
+    FAST_CASE(2, 4)    // 64, k = 8   (the reference's small test shape)
+    FAST_CASE(4, 8)    // 128, k = 16
+#undef FAST_CASE
     const int epl = ceil_div(c->D, 64);
-#define DEC_CASE(N)                                                                                              \
-    if (epl <= N) {                                                                                              \
-        launch_decode<N, XDT>(c, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated, step_count, \
-                              nblk, st);                                                                         \
-        return WSAE_OK;                                                                                          \
+#define DEC_CASE(N)                                                                                                \
+    if (epl <= N) {                                                                                                \
+        launch_decode<TW, N, XDT>(c, WdT, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,    \
+                                  step_count, nblk, st);                                                           \
+        return WSAE_OK;                                                                                            \
     }
     DEC_CASE(1) DEC_CASE(2) DEC_CASE(4) DEC_CASE(6) DEC_CASE(8) DEC_CASE(12) DEC_CASE(16) DEC_CASE(20) DEC_CASE(32)
 #undef DEC_CASE
     wsae_set_error("decode: input_dim %d too large", c->D);
     return WSAE_ERR_INVALID;
+}
+
+template <int XDT>
+static int dispatch_decode_prec(wsae_ctx* c, const float* params, const void* x, const int32_t* rows, const float* vals,
+                                const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
+                                int64_t* last_activated, const int64_t* step_count, int nblk, hipStream_t st) {
+    if (c->prec == WSAE_PREC_BF16)
+        return dispatch_decode<bf16_t, XDT>(c, c->WdT_bf16, params, x, rows, vals, idx, B, recon, want_bwd, dpre,
+                                            last_activated, step_count, nblk, st);
+    return dispatch_decode<float, XDT>(c, params + c->off[1], params, x, rows, vals, idx, B, recon, want_bwd, dpre,
+                                       last_activated, step_count, nblk, st);
 }
 
 extern "C" int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
@@ -205,10 +417,10 @@ extern "C" int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* 
     int rc;
     WSAE_PROF_BEGIN(ctx, WSAE_K_DECODE, st);
     if (x_dtype == WSAE_DT_F32)
-        rc = dispatch_decode<WSAE_DT_F32>(ctx, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,
+        rc = dispatch_decode_prec<WSAE_DT_F32>(ctx, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,
                                           step_count, nblk, st);
     else if (x_dtype == WSAE_DT_BF16)
-        rc = dispatch_decode<WSAE_DT_BF16>(ctx, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,
+        rc = dispatch_decode_prec<WSAE_DT_BF16>(ctx, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,
                                            step_count, nblk, st);
     else {
         wsae_set_error("wsae_decode_loss: unknown activation dtype %d", x_dtype);
