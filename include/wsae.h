@@ -148,15 +148,23 @@ int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t
 int wsae_input_grad(wsae_ctx* ctx, const float* params, const int32_t* idx, const float* dpre,
                     int32_t B, float* dx, void* stream);
 
-/* ---- optimizer tail (training.py:186-198) -----------------------------------------------------
+/* ---- optimizer tail (training.py:186-198, :212) -------------------------------------------------
  * global-L2 clip (clip_grad_norm_, max_norm <= 0 disables) -> AdamW (torch semantics, step is the
  * 1-based update count) -> decoder column renorm (model.py:91-96, if normalize_decoder) ->
- * refresh of the derived shadows.  grads are scaled by grad_scale first (1/world_size after a
- * SUM all-reduce).  All four buffers use the flat pack layout. */
+ * refresh of the derived shadows -> optional dead-feature scan (model.py:183-195) into stats.
+ * grads are scaled by grad_scale first (1/world_size after a SUM all-reduce).
+ * norm_from_wgrad: 1 = `grads` is exactly what the preceding wsae_weight_grads on this ctx wrote
+ *   (single GPU): the global norm comes from the partial sums that call left behind and one pass
+ *   over the gradients is saved; 0 = the gradients were touched since (all-reduce): recompute.
+ * last_activated (nullable) / step_count / dead_threshold: when given, stats->dead_count and
+ *   stats->dead_ratio are written (get_dead_feature_ratio() of training.py:212).
+ * All four buffers use the flat pack layout. */
 int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads, float* exp_avg,
                     float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step, float max_norm, float grad_scale,
-                    int32_t normalize_decoder, wsae_stats* stats, void* stream);
+                    int32_t normalize_decoder, int32_t norm_from_wgrad,
+                    const int64_t* last_activated, const int64_t* step_count,
+                    int64_t dead_threshold, wsae_stats* stats, void* stream);
 
 /* F.normalize(decoder.weight, dim=0) alone (model.py:91-96) + shadow refresh. */
 int wsae_normalize_decoder(wsae_ctx* ctx, float* params, void* stream);

@@ -93,6 +93,8 @@ struct wsae_ctx {
     int32_t* dead_list;   // [H] compacted dead feature indices (resample)
     int32_t* row_order;   // [maxB] rows sorted by error (resample)
     int n_dec_blocks;     // blocks used by the last decode launch (partials to reduce)
+    int n_sq_parts;       // global-norm partials left in part_sq by the last wsae_weight_grads
+    float* dbd2;          // [64][D] level-1 reduction of part_dbd
     size_t ws_bytes;
 };
 

@@ -79,7 +79,8 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     const size_t o_pl = cv.take(WSAE_MAX_PARTIALS * 4);
     const size_t o_p0 = cv.take(WSAE_MAX_PARTIALS * 4);
     const size_t o_pd = cv.take((size_t)WSAE_MAX_PARTIALS * D * 4);
-    const size_t o_ps = cv.take(WSAE_MAX_PARTIALS * 4);
+    const size_t o_ps = cv.take((WSAE_MAX_PARTIALS + 64) * 4);
+    const size_t o_d2 = cv.take((size_t)64 * D * 4);
     const size_t o_cn = cv.take((size_t)H * 4);
     const size_t o_ct = cv.take(64 * 4);
     const size_t o_ws = cv.take((size_t)WSAE_WGRAD_MAX_SPLIT * 2 * H * D * 4);
@@ -117,6 +118,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     c->part_l0 = (float*)(base + o_p0);
     c->part_dbd = (float*)(base + o_pd);
     c->part_sq = (float*)(base + o_ps);
+    c->dbd2 = (float*)(base + o_d2);
     c->colnorm = (float*)(base + o_cn);
     c->counters = (int32_t*)(base + o_ct);
     c->wg_slabs = (float*)(base + o_ws);

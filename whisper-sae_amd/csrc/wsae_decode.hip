@@ -6,6 +6,50 @@
 // k gathers per row are coalesced; lane l owns elements l, l+64, ... of the row.
 #include "wsae_common.h"
 
+// Block epilogue shared by both decode kernels: write this block's partial sums (loss, l0, and the
+// [D] column sums of g) and let the LAST block to arrive reduce the loss / l0 partials in fixed order
+// into the stats record.  Hand-off form (cdna guide, Guideline 16 / microarch "valid forms"): the
+// 4-byte partials are agent-scope atomic (sc1, write-through) stores, drained with vmcnt(0) before
+// the ticket add, and read back with agent-scope atomic loads -- no fences, no separate launch.
+// The [D] column sums are consumed by a later kernel, so plain stores do for them.
+template <bool BWD>
+__device__ __forceinline__ void decode_block_epilogue(float loss_acc, int l0_acc, const float* dbd_s, int D, int B,
+                                                      float* red, float* part_loss, float* part_l0, float* part_dbd,
+                                                      int32_t* ticket, wsae_stats* stats) {
+    const int lane = threadIdx.x & 63;
+    const float bl = block_sum(loss_acc, red);
+    const float b0 = block_sum(lane == 0 ? (float)l0_acc : 0.f, red);
+    if (threadIdx.x == 0) {  // write-through (sc1) stores: visible to the last arriver without a release fence
+        __hip_atomic_store(part_loss + blockIdx.x, bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part_l0 + blockIdx.x, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (BWD) {
+        for (int d = threadIdx.x; d < D; d += 256)
+            part_dbd[(int64_t)blockIdx.x * D + d] = dbd_s[d] + dbd_s[D + d] + dbd_s[2 * D + d] + dbd_s[3 * D + d];
+    }
+    __shared__ int last_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = (t == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last_s) return;
+    float a = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+        a += __hip_atomic_load(part_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c += __hip_atomic_load(part_l0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float ta = block_sum(a, red);
+    const float tc = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        stats->loss = ta / ((float)B * (float)D);
+        stats->l0 = tc / (float)B;
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+}
+
 template <typename TW, int EPL, int XDT, bool BWD, bool ROUND_DPRE>
 __global__ void __launch_bounds__(256)
 decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const float* __restrict__ bpre,
@@ -13,7 +57,7 @@ decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const fl
               const int32_t* __restrict__ idx, int B, int D, int K, float* __restrict__ recon_out,
               float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated,
               const int64_t* __restrict__ step_count, float* __restrict__ part_loss, float* __restrict__ part_l0,
-              float* __restrict__ part_dbd) {
+              float* __restrict__ part_dbd, int32_t* __restrict__ ticket, wsae_stats* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;          // [8] block reduction scratch
     float* dbd_s = (float*)smem + 8;    // [4][D]
@@ -100,11 +144,6 @@ decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const fl
         }
     }
 
-    // ---- block partials: loss / l0 reduced in fixed order by decode_finalize ----
-    const float bl = block_sum(loss_acc, red);
-    if (threadIdx.x == 0) part_loss[blockIdx.x] = bl;
-    const float b0 = block_sum(lane == 0 ? (float)l0_acc : 0.f, red);
-    if (threadIdx.x == 0) part_l0[blockIdx.x] = b0;
     if (BWD) {
         __syncthreads();
 #pragma unroll
@@ -113,10 +152,8 @@ decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const fl
             if (d < D) dbd_s[wave * D + d] = dbd[e];
         }
         __syncthreads();
-        // sum_b g joins the [D] accumulator at the head of part_dbd (zeroed by the launcher)
-        for (int d = threadIdx.x; d < D; d += 256)
-            atomicAdd(part_dbd + d, dbd_s[d] + dbd_s[D + d] + dbd_s[2 * D + d] + dbd_s[3 * D + d]);
     }
+    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, part_loss, part_l0, part_dbd, ticket, stats);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -185,7 +222,8 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
                    const int32_t* __restrict__ idx, int B, int K, float* __restrict__ recon_out,
                    float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated,
                    const int64_t* __restrict__ step_count, float* __restrict__ part_loss,
-                   float* __restrict__ part_l0, float* __restrict__ part_dbd) {
+                   float* __restrict__ part_l0, float* __restrict__ part_dbd, int32_t* __restrict__ ticket,
+                   wsae_stats* __restrict__ stats) {
     constexpr int D = 32 * EPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;        // [8]
@@ -276,10 +314,6 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
         }
     }
 
-    const float bl = block_sum(loss_acc, red);
-    if (threadIdx.x == 0) part_loss[blockIdx.x] = bl;
-    const float b0 = block_sum(lane == 0 ? (float)l0_acc : 0.f, red);
-    if (threadIdx.x == 0) part_l0[blockIdx.x] = b0;
     if (BWD) {
         __syncthreads();
         if (half == 0) {
@@ -287,43 +321,40 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
             for (int e = 0; e < EPL; ++e) dbd_s[wave * D + EPL * li + e] = dbd[e];
         }
         __syncthreads();
-        for (int d = threadIdx.x; d < D; d += 256)
-            atomicAdd(part_dbd + d, dbd_s[d] + dbd_s[D + d] + dbd_s[2 * D + d] + dbd_s[3 * D + d]);
     }
-}
-
-__global__ void __launch_bounds__(256) decode_finalize_kernel(const float* __restrict__ part_loss,
-                                                              const float* __restrict__ part_l0, int n, int B, int D,
-                                                              wsae_stats* __restrict__ stats) {
-    __shared__ float red[8];
-    float a = 0.f, c = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        a += part_loss[i];
-        c += part_l0[i];
-    }
-    const float ta = block_sum(a, red);
-    const float tc = block_sum(c, red);
-    if (threadIdx.x == 0) {
-        stats->loss = ta / ((float)B * (float)D);
-        stats->l0 = tc / (float)B;
-    }
+    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, part_loss, part_l0, part_dbd, ticket, stats);
 }
 
 // g [B][D] f32 -> gT [D][ldT] in the contraction dtype, zero-padded beyond column B.
+// 64 x 64 tiles through LDS; 16-byte reads along d, 8/16-byte packed writes along b.
 template <typename T>
 __global__ void __launch_bounds__(256) transpose_g_kernel(const float* __restrict__ g, T* __restrict__ gT, int B, int D,
                                                           int ldT) {
     __shared__ float tile[64][65];
     const int b0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int r = ty; r < 64; r += 4) {
-        const int b = b0 + r, d = d0 + tx;
-        tile[r][tx] = (b < B && d < D) ? g[(int64_t)b * D + d] : 0.f;
+    const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int bl = r16 + 16 * p, b = b0 + bl, d = d0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B && d < D) v = *(const float4*)(g + (int64_t)b * D + d);
+        tile[bl][4 * q] = v.x; tile[bl][4 * q + 1] = v.y; tile[bl][4 * q + 2] = v.z; tile[bl][4 * q + 3] = v.w;
     }
     __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int d = d0 + r, b = b0 + tx;
-        if (d < D && b < ldT) gT[(int64_t)d * ldT + b] = (T)tile[tx][r];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int dl = r16 + 16 * p, d = d0 + dl, b = b0 + 4 * q;
+        if (d < D && b < ldT) {
+            if (sizeof(T) == 2) {
+                bf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (bf16_t)tile[4 * q + i][dl];
+                *(bf16x4*)(gT + (int64_t)d * ldT + b) = o;
+            } else {
+                *(float4*)(gT + (int64_t)d * ldT + b) =
+                    make_float4(tile[4 * q][dl], tile[4 * q + 1][dl], tile[4 * q + 2][dl], tile[4 * q + 3][dl]);
+            }
+        }
     }
 }
 
@@ -331,12 +362,12 @@ __global__ void __launch_bounds__(256) transpose_g_kernel(const float* __restric
 template <typename TW, int EPL, int XDT>
 static void launch_decode(wsae_ctx* c, const TW* WdT, const float* params, const void* x, const int32_t* rows,
                           const float* vals, const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
-                          int64_t* last_activated, const int64_t* step_count, int nblk, hipStream_t st) {
+                          int64_t* last_activated, const int64_t* step_count, int nblk, wsae_stats* stats, hipStream_t st) {
     const float* bd = params + c->off[3];
     const float* bpre = params + c->off[4];
     const size_t sh = (8 + 4 * (size_t)c->D) * sizeof(float);
 #define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->D, c->K, recon, dpre, c->g, last_activated, step_count, \
-                 c->part_loss, c->part_l0, c->part_dbd
+                 c->part_loss, c->part_l0, c->part_dbd, c->counters, stats
     if (!want_bwd)
         decode_kernel<TW, EPL, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
     else if (c->prec == WSAE_PREC_BF16)
@@ -349,12 +380,12 @@ static void launch_decode(wsae_ctx* c, const TW* WdT, const float* params, const
 template <typename TW, int EPL, int KJ, int XDT>
 static void launch_decode_fast(wsae_ctx* c, const TW* WdT, const float* params, const void* x, const int32_t* rows,
                                const float* vals, const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
-                               int64_t* last_activated, const int64_t* step_count, int nblk, hipStream_t st) {
+                               int64_t* last_activated, const int64_t* step_count, int nblk, wsae_stats* stats, hipStream_t st) {
     const float* bd = params + c->off[3];
     const float* bpre = params + c->off[4];
     const size_t sh = (8 + 4 * (size_t)c->D) * sizeof(float);
 #define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->K, recon, dpre, c->g, last_activated, step_count, \
-                 c->part_loss, c->part_l0, c->part_dbd
+                 c->part_loss, c->part_l0, c->part_dbd, c->counters, stats
     if (!want_bwd)
         decode_fast_kernel<TW, EPL, KJ, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
     else if (c->prec == WSAE_PREC_BF16)
@@ -367,12 +398,12 @@ static void launch_decode_fast(wsae_ctx* c, const TW* WdT, const float* params, 
 template <typename TW, int XDT>
 static int dispatch_decode(wsae_ctx* c, const TW* WdT, const float* params, const void* x, const int32_t* rows,
                            const float* vals, const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
-                           int64_t* last_activated, const int64_t* step_count, int nblk, hipStream_t st) {
+                           int64_t* last_activated, const int64_t* step_count, int nblk, wsae_stats* stats, hipStream_t st) {
     // fast path: (D = 32*EPL, K = 2*KJ) shapes with the gathered rows held in registers
 #define FAST_CASE(E, J)                                                                                            \
     if (c->D == 32 * E && c->K == 2 * J) {                                                                         \
         launch_decode_fast<TW, E, J, XDT>(c, WdT, params, x, rows, vals, idx, B, recon, want_bwd, dpre,            \
-                                          last_activated, step_count, nblk, st);                                   \
+                                          last_activated, step_count, nblk, stats, st);                                   \
         return WSAE_OK;                                                                                            \
     }
     FAST_CASE(12, 16)  // 384, k = 32 (whisper-tiny, cfg 1-3)
@@ -383,7 +414,7 @@ static int dispatch_decode(wsae_ctx* c, const TW* WdT, const float* params, cons
 #define DEC_CASE(N)                                                                                                \
     if (epl <= N) {                                                                                                \
         launch_decode<TW, N, XDT>(c, WdT, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,    \
-                                  step_count, nblk, st);                                                           \
+                                  step_count, nblk, stats, st);                                                           \
         return WSAE_OK;                                                                                            \
     }
     DEC_CASE(1) DEC_CASE(2) DEC_CASE(4) DEC_CASE(6) DEC_CASE(8) DEC_CASE(12) DEC_CASE(16) DEC_CASE(20) DEC_CASE(32)
@@ -395,12 +426,12 @@ static int dispatch_decode(wsae_ctx* c, const TW* WdT, const float* params, cons
 template <int XDT>
 static int dispatch_decode_prec(wsae_ctx* c, const float* params, const void* x, const int32_t* rows, const float* vals,
                                 const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
-                                int64_t* last_activated, const int64_t* step_count, int nblk, hipStream_t st) {
+                                int64_t* last_activated, const int64_t* step_count, int nblk, wsae_stats* stats, hipStream_t st) {
     if (c->prec == WSAE_PREC_BF16)
         return dispatch_decode<bf16_t, XDT>(c, c->WdT_bf16, params, x, rows, vals, idx, B, recon, want_bwd, dpre,
-                                            last_activated, step_count, nblk, st);
+                                            last_activated, step_count, nblk, stats, st);
     return dispatch_decode<float, XDT>(c, params + c->off[1], params, x, rows, vals, idx, B, recon, want_bwd, dpre,
-                                       last_activated, step_count, nblk, st);
+                                       last_activated, step_count, nblk, stats, st);
 }
 
 extern "C" int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
@@ -413,15 +444,14 @@ extern "C" int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* 
     WSAE_REQUIRE(!last_activated || step_count, "wsae_decode_loss: last_activated needs step_count");
     hipStream_t st = (hipStream_t)stream;
     const int nblk = min(ceil_div(B, 4), WSAE_MAX_PARTIALS);
-    if (want_bwd) WSAE_HIP_CHECK(hipMemsetAsync(ctx->part_dbd, 0, (size_t)ctx->D * 4, st));
     int rc;
     WSAE_PROF_BEGIN(ctx, WSAE_K_DECODE, st);
     if (x_dtype == WSAE_DT_F32)
         rc = dispatch_decode_prec<WSAE_DT_F32>(ctx, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,
-                                          step_count, nblk, st);
+                                          step_count, nblk, stats, st);
     else if (x_dtype == WSAE_DT_BF16)
         rc = dispatch_decode_prec<WSAE_DT_BF16>(ctx, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,
-                                           step_count, nblk, st);
+                                           step_count, nblk, stats, st);
     else {
         wsae_set_error("wsae_decode_loss: unknown activation dtype %d", x_dtype);
         return WSAE_ERR_INVALID;
@@ -430,10 +460,6 @@ extern "C" int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* 
     WSAE_PROF_END(ctx, WSAE_K_DECODE, st);
     WSAE_LAUNCH_CHECK();
     ctx->n_dec_blocks = nblk;
-    WSAE_PROF_BEGIN(ctx, WSAE_K_DECODE_FINALIZE, st);
-    decode_finalize_kernel<<<1, 256, 0, st>>>(ctx->part_loss, ctx->part_l0, nblk, B, ctx->D, stats);
-    WSAE_PROF_END(ctx, WSAE_K_DECODE_FINALIZE, st);
-    WSAE_LAUNCH_CHECK();
     if (want_bwd) {
         const int ldT = (B + 127) / 128 * 128;
         dim3 tg(ceil_div(ldT, 64), ceil_div(ctx->D, 64));

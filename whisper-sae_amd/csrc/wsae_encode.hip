@@ -9,28 +9,63 @@
 //   xT [D][ldT]    its transpose (Bt operand of the dW_e contraction), zero beyond column B
 // 64 x 64 tiles through LDS so both the read (along d) and the write (along b) are coalesced.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float (&v)[4]) {
+    if (sizeof(T) == 2) {
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (bf16_t)v[i];
+        *(bf16x4*)p = o;
+    } else {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int XDT>
+__device__ __forceinline__ void load4(const void* x, int64_t i, float (&v)[4]) {
+    if (XDT == WSAE_DT_BF16) {
+        const bf16x4 t = *(const bf16x4*)((const bf16_t*)x + i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (float)t[q];
+    } else {
+        const float4 t = *(const float4*)((const float*)x + i);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+}
+
 template <int XDT, typename T>
 __global__ void __launch_bounds__(256) stage_batch_kernel(const void* __restrict__ x, const int32_t* __restrict__ rows,
                                                           const float* __restrict__ bpre, T* __restrict__ xb,
                                                           T* __restrict__ xT, int B, int D, int ldT) {
     __shared__ float tile[64][65];
     const int b0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty 0..3
-    for (int r = ty; r < 64; r += 4) {
-        const int b = b0 + r, d = d0 + tx;
-        float v = 0.f;
+    const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;  // 16 threads x 4 elements span the tile width
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int bl = r16 + 16 * p, b = b0 + bl, d = d0 + 4 * q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (b < B && d < D) {
             const int64_t src = rows ? (int64_t)rows[b] : (int64_t)b;
-            v = load_act<XDT>(x, src * D + d);
-            if (sizeof(T) == 4) v -= bpre[d];
-            xb[(int64_t)b * D + d] = (T)v;
+            load4<XDT>(x, src * D + d, v);
+            if (sizeof(T) == 4) {
+                const float4 bp = *(const float4*)(bpre + d);
+                v[0] -= bp.x; v[1] -= bp.y; v[2] -= bp.z; v[3] -= bp.w;
+            }
+            store4<T>(xb + (int64_t)b * D + d, v);
         }
-        tile[r][tx] = v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[bl][4 * q + i] = v[i];
     }
     __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int d = d0 + r, b = b0 + tx;
-        if (d < D && b < ldT) xT[(int64_t)d * ldT + b] = (T)tile[tx][r];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int dl = r16 + 16 * p, d = d0 + dl, b = b0 + 4 * q;
+        if (d < D && b < ldT) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (T)tile[4 * q + i][dl];
+            store4<T>(xT + (int64_t)d * ldT + b, v);
+        }
     }
 }
 

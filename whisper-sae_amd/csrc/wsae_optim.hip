@@ -26,7 +26,8 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
 // min(1, max_norm/(||g||+1e-6)) (torch.nn.utils.clip_grad_norm_).
 __global__ void __launch_bounds__(256)
 adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-             int64_t n4, const float* __restrict__ part_sq, int nparts, float max_norm, float grad_scale, float lr_wd,
+             int64_t n4, const float* __restrict__ part_sq, int nparts, float part_scale, float max_norm,
+             float grad_scale, float lr_wd,
              float beta1, float beta2, float eps, float step_size, float bc2_sqrt, wsae_stats* __restrict__ stats) {
     __shared__ float red[8];
     __shared__ float coef_s;
@@ -34,7 +35,7 @@ adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restri
     for (int i = threadIdx.x; i < nparts; i += 256) a += part_sq[i];
     const float tot = block_sum(a, red);
     if (threadIdx.x == 0) {
-        const float nrm = sqrtf(tot);
+        const float nrm = sqrtf(tot) * part_scale;  // partials may be of the unscaled gradients
         float coef = 1.f;
         if (max_norm > 0.f) coef = fminf(1.f, max_norm / (nrm + 1e-6f));
         coef_s = coef * grad_scale;
@@ -68,67 +69,156 @@ adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restri
     }
 }
 
-// ---- per-feature-row maintenance: decoder unit norm (+ shadows via wsae_prepare_launch) ----------
-// W_dT[h,:] /= max(||W_dT[h,:]||_2, 1e-12)   == F.normalize(decoder.weight, dim=0), column h
-__global__ void __launch_bounds__(256) rownorm_kernel(float* __restrict__ WdT, int H, int D) {
-    const int lane = threadIdx.x & 63;
-    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (h >= H) return;
-    float* row = WdT + (int64_t)h * D;
-    float s = 0.f;
-    for (int d = lane * 2; d < D; d += 128) {
-        const float2 w = *(const float2*)(row + d);
-        s += w.x * w.x + w.y * w.y;
+// ---- per-feature-row maintenance, one wave per feature row h ---------------------------------------
+//   NORMALIZE: W_dT[h,:] /= max(||W_dT[h,:]||_2, 1e-12)   == F.normalize(decoder.weight, dim=0), column h
+//   SHADOW   : bf16 shadows of W_e[h,:] and W_dT[h,:], folded bias c[h] = b_e[h] - bf16(W_e)[h,:] . b_pre
+//   dead scan: (step_count - last_activated[h]) > threshold counted into the stats record by the last
+//              block to arrive (integer atomics: deterministic)        model.py:183-195
+#define REFRESH_ROWS 8  // feature rows per block (2 per wave): few blocks -> few same-address atomics
+template <bool NORMALIZE, bool SHADOW>
+__global__ void __launch_bounds__(256)
+refresh_kernel(const float* __restrict__ We, float* __restrict__ WdT, const float* __restrict__ be,
+               const float* __restrict__ bpre, bf16_t* __restrict__ We16, bf16_t* __restrict__ WdT16,
+               float* __restrict__ cfold, int H, int D, const int64_t* __restrict__ last, const int64_t* __restrict__ step_count,
+               int64_t thr, int32_t* __restrict__ counters, wsae_stats* __restrict__ stats) {
+    __shared__ int dead_s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int dead = 0;
+    constexpr int RPW = REFRESH_ROWS / 4;
+    const int hbase = blockIdx.x * REFRESH_ROWS + wave * RPW;
+    // both rows of the wave are fetched up front (<= 16 float2 per lane per row covers D <= 2048)
+    float2 wd[RPW][16], we[RPW][16];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int h = min(hbase + r, H - 1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int d = lane * 2 + 128 * i;
+            if (d < D) {
+                wd[r][i] = *(const float2*)(WdT + (int64_t)h * D + d);
+                if (SHADOW) we[r][i] = *(const float2*)(We + (int64_t)h * D + d);
+            }
+        }
     }
-    s = wave_sum(s);
-    const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
-    for (int d = lane * 2; d < D; d += 128) {
-        float2 w = *(float2*)(row + d);
-        w.x *= inv;
-        w.y *= inv;
-        *(float2*)(row + d) = w;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int h = hbase + r;
+        if (h >= H) break;
+        float inv = 1.f;
+        if (NORMALIZE) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (lane * 2 + 128 * i < D) s += wd[r][i].x * wd[r][i].x + wd[r][i].y * wd[r][i].y;
+            s = wave_sum(s);
+            inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int d = lane * 2 + 128 * i;
+            if (d < D) {
+                float2 w = wd[r][i];
+                if (NORMALIZE) {
+                    w.x *= inv;
+                    w.y *= inv;
+                    *(float2*)(WdT + (int64_t)h * D + d) = w;
+                }
+                if (SHADOW) {
+                    WdT16[(int64_t)h * D + d] = (bf16_t)w.x;
+                    WdT16[(int64_t)h * D + d + 1] = (bf16_t)w.y;
+                    const bf16_t e0 = (bf16_t)we[r][i].x, e1 = (bf16_t)we[r][i].y;
+                    We16[(int64_t)h * D + d] = e0;
+                    We16[(int64_t)h * D + d + 1] = e1;
+                    const float2 bp = *(const float2*)(bpre + d);
+                    dot = fmaf((float)e0, bp.x, dot);
+                    dot = fmaf((float)e1, bp.y, dot);
+                }
+            }
+        }
+        if (SHADOW) {
+            dot = wave_sum(dot);
+            if (lane == 0) cfold[h] = be[h] - dot;
+        }
+        if (last) dead += ((*step_count - last[h]) > thr) ? 1 : 0;
     }
+    if (!last) return;
+    if (lane == 0) dead_s[wave] = dead;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // one 64-bit atomic per block: low word accumulates the dead count, high word counts arrivals
+        unsigned long long* c64 = (unsigned long long*)(counters + 2);
+        const unsigned long long add = (1ull << 32) | (unsigned long long)(dead_s[0] + dead_s[1] + dead_s[2] + dead_s[3]);
+        const unsigned long long old = __hip_atomic_fetch_add(c64, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old >> 32) == gridDim.x - 1) {
+            const int tot = (int)((old + add) & 0xFFFFFFFFull);
+            __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stats->dead_count = tot;
+            stats->dead_ratio = (float)tot / (float)H;
+        }
+    }
+}
+
+static int launch_refresh(wsae_ctx* ctx, float* params, bool normalize, const int64_t* last, const int64_t* step_count,
+                          int64_t thr, wsae_stats* stats, hipStream_t st) {
+    const bool shadow = ctx->prec == WSAE_PREC_BF16;
+    if (!normalize && !shadow && !last) return WSAE_OK;
+    const int nb = ceil_div(ctx->H, REFRESH_ROWS);
+#define RF_ARGS params + ctx->off[0], params + ctx->off[1], params + ctx->off[2], params + ctx->off[4], ctx->We_bf16, \
+                ctx->WdT_bf16, ctx->c_fold, ctx->H, ctx->D, last, step_count, thr, ctx->counters, stats
+    WSAE_PROF_BEGIN(ctx, WSAE_K_ROWNORM, st);
+    if (normalize && shadow) refresh_kernel<true, true><<<nb, 256, 0, st>>>(RF_ARGS);
+    else if (normalize) refresh_kernel<true, false><<<nb, 256, 0, st>>>(RF_ARGS);
+    else if (shadow) refresh_kernel<false, true><<<nb, 256, 0, st>>>(RF_ARGS);
+    else refresh_kernel<false, false><<<nb, 256, 0, st>>>(RF_ARGS);
+    WSAE_PROF_END(ctx, WSAE_K_ROWNORM, st);
+#undef RF_ARGS
+    WSAE_LAUNCH_CHECK();
+    return WSAE_OK;
 }
 
 extern "C" int wsae_normalize_decoder(wsae_ctx* ctx, float* params, void* stream) {
     WSAE_REQUIRE(ctx && params, "wsae_normalize_decoder: null argument");
-    hipStream_t st = (hipStream_t)stream;
-    rownorm_kernel<<<ceil_div(ctx->H, 4), 256, 0, st>>>(params + ctx->off[1], ctx->H, ctx->D);
-    WSAE_LAUNCH_CHECK();
-    return wsae_prepare_launch(ctx, params, st);
+    return launch_refresh(ctx, params, true, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
-                               float max_norm, float grad_scale, int32_t normalize_decoder, wsae_stats* stats,
-                               void* stream) {
+                               float max_norm, float grad_scale, int32_t normalize_decoder, int32_t norm_from_wgrad,
+                               const int64_t* last_activated, const int64_t* step_count, int64_t dead_threshold,
+                               wsae_stats* stats, void* stream) {
     WSAE_REQUIRE(ctx && params && grads && exp_avg && exp_avg_sq, "wsae_adamw_step: null argument");
     WSAE_REQUIRE(step >= 1, "wsae_adamw_step: step is the 1-based update count, got %d", step);
     WSAE_REQUIRE(ctx->P % 4 == 0, "wsae_adamw_step: pack size %lld not a multiple of 4", (long long)ctx->P);
+    WSAE_REQUIRE(!last_activated || (step_count && stats), "wsae_adamw_step: the dead scan needs step_count and stats");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n4 = ctx->P / 4;
-    const int nb = (int)min((int64_t)WSAE_MAX_PARTIALS, ceil_div64(n4, 256 * 2));
-    WSAE_PROF_BEGIN(ctx, WSAE_K_SQNORM, st);
-    sqnorm_kernel<<<nb, 256, 0, st>>>(grads, n4, grad_scale, ctx->part_sq);
-    WSAE_PROF_END(ctx, WSAE_K_SQNORM, st);
-    WSAE_LAUNCH_CHECK();
+    int nparts;
+    float part_scale;
+    if (norm_from_wgrad) {  // partial sums of squares were left by wsae_weight_grads (grads untouched since)
+        WSAE_REQUIRE(ctx->n_sq_parts > 0, "wsae_adamw_step: norm_from_wgrad without a preceding wsae_weight_grads");
+        nparts = ctx->n_sq_parts;
+        part_scale = grad_scale;
+    } else {
+        nparts = (int)min((int64_t)WSAE_MAX_PARTIALS, ceil_div64(n4, 256 * 2));
+        part_scale = 1.f;
+        WSAE_PROF_BEGIN(ctx, WSAE_K_SQNORM, st);
+        sqnorm_kernel<<<nparts, 256, 0, st>>>(grads, n4, grad_scale, ctx->part_sq);
+        WSAE_PROF_END(ctx, WSAE_K_SQNORM, st);
+        WSAE_LAUNCH_CHECK();
+    }
+    ctx->n_sq_parts = 0;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     const int nb2 = (int)min((int64_t)2048, ceil_div64(n4, 256));
     WSAE_PROF_BEGIN(ctx, WSAE_K_ADAMW, st);
-    adamw_kernel<<<nb2, 256, 0, st>>>(params, grads, exp_avg, exp_avg_sq, n4, ctx->part_sq, nb, max_norm, grad_scale,
-                                      lr * weight_decay, beta1, beta2, eps, step_size, bc2_sqrt, stats);
+    adamw_kernel<<<nb2, 256, 0, st>>>(params, grads, exp_avg, exp_avg_sq, n4, ctx->part_sq, nparts, part_scale, max_norm,
+                                      grad_scale, lr * weight_decay, beta1, beta2, eps, step_size, bc2_sqrt, stats);
     WSAE_PROF_END(ctx, WSAE_K_ADAMW, st);
     WSAE_LAUNCH_CHECK();
-    if (normalize_decoder) {
-        WSAE_PROF_BEGIN(ctx, WSAE_K_ROWNORM, st);
-        rownorm_kernel<<<ceil_div(ctx->H, 4), 256, 0, st>>>(params + ctx->off[1], ctx->H, ctx->D);
-        WSAE_PROF_END(ctx, WSAE_K_ROWNORM, st);
-        WSAE_LAUNCH_CHECK();
-    }
-    return wsae_prepare_launch(ctx, params, st);
+    return launch_refresh(ctx, params, normalize_decoder != 0, last_activated, step_count, dead_threshold, stats, st);
 }
 
 // ---- dead features -------------------------------------------------------------------------------

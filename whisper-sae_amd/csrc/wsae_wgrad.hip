@@ -179,7 +179,10 @@ wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid
 template <bool FOLD>
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, const float* __restrict__ dbe_slab, int nsplit,
-                    const float* __restrict__ bpre, float* __restrict__ grads, float* __restrict__ dbe_out, int H, int D) {
+                    const float* __restrict__ bpre, float* __restrict__ grads, float* __restrict__ dbe_out, int H, int D,
+                    float* __restrict__ part_sq) {
+    __shared__ float red[8];
+    float sq = 0.f;  // sum of squares of everything this block writes (global-norm partial)
     const int64_t n4 = (int64_t)2 * H * D / 4;
     const int64_t hd4 = (int64_t)H * D / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -193,50 +196,102 @@ wgrad_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, const 
             const int h = (int)(e / D), d = (int)(e - (int64_t)h * D);
             float be = 0.f;
             for (int s = 0; s < nsplit; ++s) be += dbe_slab[(int64_t)s * H + h];
-            if (d == 0) dbe_out[h] = be;
+            if (d == 0) {
+                dbe_out[h] = be;
+                sq = fmaf(be, be, sq);
+            }
             if (FOLD) {
                 const float4 bp = *(const float4*)(bpre + d);
                 a.x -= be * bp.x; a.y -= be * bp.y; a.z -= be * bp.z; a.w -= be * bp.w;
             }
         }
         ((float4*)grads)[i] = a;
+        sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
     }
+    const float t = block_sum(sq, red);
+    if (threadIdx.x == 0) part_sq[blockIdx.x] = t;
 }
 
-// db_pre partials: part[blk][d] = sum_{h in blk's 32 rows} db_e[h] * W[h][d]   (no atomics)
+// blocks [0, nblk_h): db_pre partials  part[blk][d] = sum_{h in blk's 128 rows} db_e[h] * W[h][d]
+// blocks [nblk_h, nblk_h + 64): level-1 reduction of the decode launch's column sums of g,
+//   dbd2[j][d] = sum over decode blocks i = j, j+64, ... of part_dbd[i][d]      (no atomics anywhere)
+// Loads are issued 32 (resp. 16) at a time: a one-at-a-time loop here is pure L2 latency.
+#define DBPRE_ROWS 128
+#define DBD_L1 64
 template <typename TW>
-__global__ void __launch_bounds__(256) dbpre_partial_kernel(const TW* __restrict__ W, const float* __restrict__ dbe,
-                                                            float* __restrict__ part, int H, int D) {
-    __shared__ float e_s[32];
-    const int h0 = blockIdx.x * 32;
-    if (threadIdx.x < 32) e_s[threadIdx.x] = (h0 + (int)threadIdx.x < H) ? dbe[h0 + threadIdx.x] : 0.f;
+__global__ void __launch_bounds__(256)
+dbpre_partial_kernel(const TW* __restrict__ W, const float* __restrict__ dbe, float* __restrict__ part, int H, int D,
+                     int nblk_h, const float* __restrict__ part_dbd, int n_dec, float* __restrict__ dbd2) {
+    if ((int)blockIdx.x >= nblk_h) {
+        const int j = blockIdx.x - nblk_h;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float v[WSAE_MAX_PARTIALS / DBD_L1];
+#pragma unroll
+            for (int t = 0; t < WSAE_MAX_PARTIALS / DBD_L1; ++t) {
+                const int i = j + DBD_L1 * t;
+                v[t] = i < n_dec ? part_dbd[(int64_t)i * D + d] : 0.f;
+            }
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < WSAE_MAX_PARTIALS / DBD_L1; ++t) a += v[t];
+            dbd2[(int64_t)j * D + d] = a;
+        }
+        return;
+    }
+    __shared__ float e_s[DBPRE_ROWS];
+    const int h0 = blockIdx.x * DBPRE_ROWS;
+    if (threadIdx.x < DBPRE_ROWS) e_s[threadIdx.x] = (h0 + (int)threadIdx.x < H) ? dbe[h0 + threadIdx.x] : 0.f;
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256) {
         float a = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i)
-            if (h0 + i < H) a = fmaf(e_s[i], (float)W[(int64_t)(h0 + i) * D + d], a);
+        for (int r0 = 0; r0 < DBPRE_ROWS; r0 += 32) {
+            float w[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) w[i] = (float)W[(int64_t)min(h0 + r0 + i, H - 1) * D + d];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) a = fmaf(e_s[r0 + i], w[i], a);
+        }
         part[(int64_t)blockIdx.x * D + d] = a;
     }
 }
 
-// db_d = sum_b g (accumulated by the decode launch); db_pre = db_d - sum_blk part[blk]
-__global__ void __launch_bounds__(256) bias_finish_kernel(const float* __restrict__ dbd_acc, const float* __restrict__ part,
+// db_d = sum of the 64 level-1 rows; db_pre = db_d - sum_blk part[blk]; plus their share of the
+// global-norm partials (part_sq[sq_base + blockIdx.x]).  4 thread groups split the partial rows.
+__global__ void __launch_bounds__(256) bias_finish_kernel(const float* __restrict__ dbd2, const float* __restrict__ part,
                                                           int nblk, float* __restrict__ dbd, float* __restrict__ dbpre,
-                                                          int D) {
-    __shared__ float red[4][64];
+                                                          int D, float* __restrict__ part_sq, int sq_base) {
+    __shared__ float red[2][4][64];
+    __shared__ float red2[8];
     const int dl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int d = blockIdx.x * 64 + dl;
-    float a = 0.f;
-    if (d < D)
-        for (int b = grp; b < nblk; b += 4) a += part[(int64_t)b * D + d];
-    red[grp][dl] = a;
-    __syncthreads();
-    if (grp == 0 && d < D) {
-        const float s = dbd_acc[d];
-        dbd[d] = s;
-        dbpre[d] = s - (red[0][dl] + red[1][dl] + red[2][dl] + red[3][dl]);
+    float a = 0.f, s = 0.f;
+    if (d < D) {
+        for (int b0 = grp * 8; b0 < nblk; b0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (b0 + i < nblk) ? part[(int64_t)(b0 + i) * D + d] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a += v[i];
+        }
+        float v[DBD_L1 / 4];
+#pragma unroll
+        for (int i = 0; i < DBD_L1 / 4; ++i) v[i] = dbd2[(int64_t)(grp * (DBD_L1 / 4) + i) * D + d];
+#pragma unroll
+        for (int i = 0; i < DBD_L1 / 4; ++i) s += v[i];
     }
+    red[0][grp][dl] = a;
+    red[1][grp][dl] = s;
+    __syncthreads();
+    float sq = 0.f;
+    if (grp == 0 && d < D) {
+        const float sd = red[1][0][dl] + red[1][1][dl] + red[1][2][dl] + red[1][3][dl];
+        const float p = sd - (red[0][0][dl] + red[0][1][dl] + red[0][2][dl] + red[0][3][dl]);
+        dbd[d] = sd;
+        dbpre[d] = p;
+        sq = sd * sd + p * p;
+    }
+    const float t = block_sum(sq, red2);
+    if (threadIdx.x == 0) part_sq[sq_base + blockIdx.x] = t;
 }
 
 template <typename T>
@@ -282,24 +337,30 @@ extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void*
 
     float* dbe = grads + ctx->off[2];
     const float* bpre = params + ctx->off[4];
-    const int nrb = (int)min((int64_t)2048, ceil_div64(slab_stride / 4, 256));
+    const int nrb = (int)min((int64_t)WSAE_MAX_PARTIALS, ceil_div64(slab_stride / 4, 256));
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD_REDUCE, st);
     if (ctx->prec == WSAE_PREC_BF16)
-        wgrad_reduce_kernel<true><<<nrb, 256, 0, st>>>(out, slab_stride, ctx->dbe_slab, nsplit, bpre, grads, dbe, H, D);
+        wgrad_reduce_kernel<true><<<nrb, 256, 0, st>>>(out, slab_stride, ctx->dbe_slab, nsplit, bpre, grads, dbe, H, D,
+                                                       ctx->part_sq);
     else
-        wgrad_reduce_kernel<false><<<nrb, 256, 0, st>>>(out, slab_stride, ctx->dbe_slab, nsplit, bpre, grads, dbe, H, D);
+        wgrad_reduce_kernel<false><<<nrb, 256, 0, st>>>(out, slab_stride, ctx->dbe_slab, nsplit, bpre, grads, dbe, H, D,
+                                                        ctx->part_sq);
     WSAE_PROF_END(ctx, WSAE_K_WGRAD_REDUCE, st);
     WSAE_LAUNCH_CHECK();
 
-    const int nblk = ceil_div(H, 32);
+    const int nblk = ceil_div(H, DBPRE_ROWS);
+    const int nfin = ceil_div(D, 64);
     WSAE_PROF_BEGIN(ctx, WSAE_K_BIAS_GRADS, st);
     if (ctx->prec == WSAE_PREC_BF16)
-        dbpre_partial_kernel<bf16_t><<<nblk, 256, 0, st>>>(ctx->We_bf16, dbe, ctx->dbpre_part, H, D);
+        dbpre_partial_kernel<bf16_t><<<nblk + DBD_L1, 256, 0, st>>>(ctx->We_bf16, dbe, ctx->dbpre_part, H, D, nblk,
+                                                                ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2);
     else
-        dbpre_partial_kernel<float><<<nblk, 256, 0, st>>>(params + ctx->off[0], dbe, ctx->dbpre_part, H, D);
-    bias_finish_kernel<<<ceil_div(D, 64), 256, 0, st>>>(ctx->part_dbd, ctx->dbpre_part, nblk, grads + ctx->off[3],
-                                                        grads + ctx->off[4], D);
+        dbpre_partial_kernel<float><<<nblk + DBD_L1, 256, 0, st>>>(params + ctx->off[0], dbe, ctx->dbpre_part, H, D, nblk,
+                                                               ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2);
+    bias_finish_kernel<<<nfin, 256, 0, st>>>(ctx->dbd2, ctx->dbpre_part, nblk, grads + ctx->off[3], grads + ctx->off[4],
+                                             D, ctx->part_sq, nrb);
     WSAE_PROF_END(ctx, WSAE_K_BIAS_GRADS, st);
     WSAE_LAUNCH_CHECK();
+    ctx->n_sq_parts = nrb + nfin;  // wsae_adamw_step(norm_from_wgrad = 1) sums these
     return WSAE_OK;
 }

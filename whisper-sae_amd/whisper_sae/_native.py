@@ -56,7 +56,8 @@ SIGNATURES = {
     "wsae_decode_loss": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
     "wsae_weight_grads": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     "wsae_input_grad": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p]),
-    "wsae_adamw_step": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _p, _p]),
+    "wsae_adamw_step": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _i32,
+                                  _p, _p, _i64, _p, _p]),
     "wsae_normalize_decoder": (C.c_int, [_p, _p, _p]),
     "wsae_dead_scan": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
     "wsae_row_errors": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _p, _p]),

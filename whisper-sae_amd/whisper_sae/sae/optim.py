@@ -67,20 +67,24 @@ class FusedAdamW(Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, *, precision: int = N.PREC_FP32, max_norm: float = 0.0, grad_scale: float = 1.0,
-             normalize_decoder: bool = False, batch: int = 64):
+             normalize_decoder: bool = False, batch: int = 64, norm_from_wgrad: bool = False, dead_scan: bool = False):
         """Apply one update from ``self.grads`` (filled by ``wsae_weight_grads``)."""
         if closure is not None:
             raise NotImplementedError("FusedAdamW does not take a closure")
         eng = self.module.bind()
         self._ensure_state(eng)
         g = self.param_groups[0]
+        mod = self.module
         self._t += 1
         handle = eng.ctx(precision, batch)
         N.check(eng.lib.wsae_adamw_step(handle, eng.pack.data_ptr(), self.grads.data_ptr(), self._m.data_ptr(),
                                         self._v.data_ptr(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                         float(g["eps"]), float(g["weight_decay"]), self._t, float(max_norm),
-                                        float(grad_scale), 1 if normalize_decoder else 0, eng.stats.data_ptr(),
-                                        eng.stream()), "wsae_adamw_step")
+                                        float(grad_scale), 1 if normalize_decoder else 0, 1 if norm_from_wgrad else 0,
+                                        mod.feature_last_activated.data_ptr() if dead_scan else 0,
+                                        mod.step_count.data_ptr() if dead_scan else 0,
+                                        int(mod.dead_feature_threshold) if dead_scan else 0,
+                                        eng.stats.data_ptr(), eng.stream()), "wsae_adamw_step")
         eng.mark_fresh(precision)
         for st in self.state.values():
             if "step" in st:

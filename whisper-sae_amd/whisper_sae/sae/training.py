@@ -31,6 +31,7 @@ from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
 
 from .. import _native as N
 from ..config import TrainingConfig
+from ..distributed import sync_gradients
 from .engine import _dtype_code, require_device_tensor
 from .optim import FusedAdamW
 
@@ -158,12 +159,6 @@ class SAETrainer:
         self.scheduler = SequentialLR(self.optimizer, schedulers=[ramp, decay], milestones=[warm])
 
     # -- the step ------------------------------------------------------------------------------------
-    def _world(self):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return dist, dist.get_world_size()
-        return None, 1
-
     def train_step(self, batch) -> TrainingMetrics:
         """One optimisation step on ``batch`` ([B, D] tensor, or a tuple/list whose first item is one).
 
@@ -207,24 +202,18 @@ class SAETrainer:
         N.check(lib.wsae_weight_grads(handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(),
                                       w["dpre"].data_ptr(), B, opt.grads.data_ptr(), st), "wsae_weight_grads")
         eng.generation += 1
-        dist, world = self._world()
-        if dist is not None:  # data parallel: mean of the per-rank mean-gradients, agreed dead-feature clock
-            dist.all_reduce(opt.grads, op=dist.ReduceOp.SUM)
-            dist.all_reduce(model.feature_last_activated, op=dist.ReduceOp.MAX)
-        opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=1.0 / world,
-                 normalize_decoder=True, batch=B)
+        # data parallel: mean of the per-rank mean-gradients + agreed dead-feature clock (RCCL all-reduces)
+        grad_scale = sync_gradients(opt.grads, model.feature_last_activated)
+        opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=grad_scale,
+                 normalize_decoder=True, batch=B, norm_from_wgrad=(grad_scale == 1.0), dead_scan=True)
         self._token = model.param_token()
-        lr_used = opt.param_groups[0]["lr"]
         if self.scheduler is not None:
             self.scheduler.step()
         self.global_step += 1
-        N.check(lib.wsae_dead_scan(handle, model.feature_last_activated.data_ptr(), step_ptr,
-                                   int(model.dead_feature_threshold), 0, stats, st), "wsae_dead_scan")
         rec = self._records.next()
         rec.copy_(eng.stats, non_blocking=True)
         metrics = _PendingMetrics(rec, torch.cuda.current_stream(eng.device), opt.param_groups[0]["lr"],
                                   self.global_step)
-        del lr_used
         if self.resample_dead:
             self._maybe_resample_dead_features()
         return metrics
