@@ -224,16 +224,19 @@ __global__ void __launch_bounds__(256) prepare_kernel(const float* __restrict__ 
     const float* drow = WdT + (int64_t)h * D;
     bf16_t* odrow = WdT16 + (int64_t)h * D;
     float dot = 0.f;
-    for (int d = lane * 2; d < D; d += 128) {
-        const float2 wd = *(const float2*)(drow + d);
-        odrow[d] = (bf16_t)wd.x;
-        odrow[d + 1] = (bf16_t)wd.y;
-        const float2 w = *(const float2*)(row + d);
-        const bf16_t w0 = (bf16_t)w.x, w1 = (bf16_t)w.y;
-        orow[d] = w0;
-        orow[d + 1] = w1;
-        dot = fmaf((float)w0, bpre[d], dot);
-        dot = fmaf((float)w1, bpre[d + 1], dot);
+    for (int d = lane * 4; d < D; d += 256) {
+        const float4 wd = *(const float4*)(drow + d);
+        bf16x4 o, e;
+        o[0] = (bf16_t)wd.x; o[1] = (bf16_t)wd.y; o[2] = (bf16_t)wd.z; o[3] = (bf16_t)wd.w;
+        *(bf16x4*)(odrow + d) = o;
+        const float4 w = *(const float4*)(row + d);
+        e[0] = (bf16_t)w.x; e[1] = (bf16_t)w.y; e[2] = (bf16_t)w.z; e[3] = (bf16_t)w.w;
+        *(bf16x4*)(orow + d) = e;
+        const float4 bp = *(const float4*)(bpre + d);
+        dot = fmaf((float)e[0], bp.x, dot);
+        dot = fmaf((float)e[1], bp.y, dot);
+        dot = fmaf((float)e[2], bp.z, dot);
+        dot = fmaf((float)e[3], bp.w, dot);
     }
     dot = wave_sum(dot);
     if (lane == 0) cfold[h] = be[h] - dot;

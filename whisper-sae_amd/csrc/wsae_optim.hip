@@ -86,17 +86,18 @@ refresh_kernel(const float* __restrict__ We, float* __restrict__ WdT, const floa
     int dead = 0;
     constexpr int RPW = REFRESH_ROWS / 4;
     const int hbase = blockIdx.x * REFRESH_ROWS + wave * RPW;
-    // both rows of the wave are fetched up front (<= 16 float2 per lane per row covers D <= 2048)
-    float2 wd[RPW][16], we[RPW][16];
+    // both rows of the wave are fetched up front (<= 8 float4 per lane per row covers D <= 2048);
+    // every store is 8 or 16 bytes per lane (2-byte bf16 stores made this kernel store-issue bound)
+    float4 wd[RPW][8], we[RPW][8];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int h = min(hbase + r, H - 1);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int d = lane * 2 + 128 * i;
+        for (int i = 0; i < 8; ++i) {
+            const int d = lane * 4 + 256 * i;
             if (d < D) {
-                wd[r][i] = *(const float2*)(WdT + (int64_t)h * D + d);
-                if (SHADOW) we[r][i] = *(const float2*)(We + (int64_t)h * D + d);
+                wd[r][i] = *(const float4*)(WdT + (int64_t)h * D + d);
+                if (SHADOW) we[r][i] = *(const float4*)(We + (int64_t)h * D + d);
             }
         }
     }
@@ -108,31 +109,36 @@ refresh_kernel(const float* __restrict__ We, float* __restrict__ WdT, const floa
         if (NORMALIZE) {
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (lane * 2 + 128 * i < D) s += wd[r][i].x * wd[r][i].x + wd[r][i].y * wd[r][i].y;
+            for (int i = 0; i < 8; ++i)
+                if (lane * 4 + 256 * i < D) {
+                    const float4 w = wd[r][i];
+                    s += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+                }
             s = wave_sum(s);
             inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
         }
         float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int d = lane * 2 + 128 * i;
+        for (int i = 0; i < 8; ++i) {
+            const int d = lane * 4 + 256 * i;
             if (d < D) {
-                float2 w = wd[r][i];
+                float4 w = wd[r][i];
                 if (NORMALIZE) {
-                    w.x *= inv;
-                    w.y *= inv;
-                    *(float2*)(WdT + (int64_t)h * D + d) = w;
+                    w.x *= inv; w.y *= inv; w.z *= inv; w.w *= inv;
+                    *(float4*)(WdT + (int64_t)h * D + d) = w;
                 }
                 if (SHADOW) {
-                    WdT16[(int64_t)h * D + d] = (bf16_t)w.x;
-                    WdT16[(int64_t)h * D + d + 1] = (bf16_t)w.y;
-                    const bf16_t e0 = (bf16_t)we[r][i].x, e1 = (bf16_t)we[r][i].y;
-                    We16[(int64_t)h * D + d] = e0;
-                    We16[(int64_t)h * D + d + 1] = e1;
-                    const float2 bp = *(const float2*)(bpre + d);
-                    dot = fmaf((float)e0, bp.x, dot);
-                    dot = fmaf((float)e1, bp.y, dot);
+                    bf16x4 o, e;
+                    o[0] = (bf16_t)w.x; o[1] = (bf16_t)w.y; o[2] = (bf16_t)w.z; o[3] = (bf16_t)w.w;
+                    *(bf16x4*)(WdT16 + (int64_t)h * D + d) = o;
+                    const float4 ev = we[r][i];
+                    e[0] = (bf16_t)ev.x; e[1] = (bf16_t)ev.y; e[2] = (bf16_t)ev.z; e[3] = (bf16_t)ev.w;
+                    *(bf16x4*)(We16 + (int64_t)h * D + d) = e;
+                    const float4 bp = *(const float4*)(bpre + d);
+                    dot = fmaf((float)e[0], bp.x, dot);
+                    dot = fmaf((float)e[1], bp.y, dot);
+                    dot = fmaf((float)e[2], bp.z, dot);
+                    dot = fmaf((float)e[3], bp.w, dot);
                 }
             }
         }
