@@ -20,6 +20,10 @@ from oracle import synth
 
 pytestmark = pytest.mark.gpu
 
+from pathlib import Path  # noqa: E402
+
+GOLDEN_ROOT = Path(__file__).resolve().parents[1]
+
 KEYS = ("encoder.weight", "encoder.bias", "decoder.weight", "decoder.bias", "b_pre")
 
 
@@ -130,7 +134,6 @@ class TestGradsCfg2:
         assert rel(got["W_d"].reshape(-1)[g2["pos_d"]], g2["W_d_samples"]) < tol_ref * 5
         # input gradient: dL/dx = dpre W_e - g   (fp32 oracle)
         if mode == "fp32":
-            dx = ora["dpre_dense"] if "dpre_dense" in ora else None
             hidden_mask = fwd["hidden"] > 0
             g64 = ora["g"].astype(np.float64)
             dh = g64 @ st.W_d.astype(np.float64)
@@ -388,3 +391,37 @@ class TestScaleProperties:
         cn = m.decoder.weight.norm(dim=0)
         assert torch.allclose(cn, torch.ones_like(cn), atol=1e-5)
         assert tr.metrics_history == [] and tr.global_step == 21
+
+
+class TestEndToEnd:
+    """scripts/train.py + FeatureCache + RingLoader + SAETrainer.train (cfg-1 plumbing, on the GPU)."""
+
+    def test_cli_trains_from_a_cache(self, device, tmp_path):
+        import importlib.util
+        import json
+        from whisper_sae.config import DataConfig, ExperimentConfig, SAEConfig, TrainingConfig, WandbConfig, WhisperConfig
+        from whisper_sae.data import FeatureCache
+        cfg = ExperimentConfig(
+            sae=SAEConfig(expansion_factor=8, k=32, dead_feature_threshold=1000),
+            training=TrainingConfig(batch_size=64, learning_rate=1e-3, epochs=3, warmup_steps=100, use_amp=True,
+                                    checkpoint_every=2, num_workers=0),
+            data=DataConfig(cache_dir=tmp_path / "cache"), wandb=WandbConfig(enabled=False),
+            encoder_layers=[0], decoder_layers=[], output_dir=tmp_path / "out", experiment_name="e2e")
+        cfg.to_yaml(tmp_path / "cfg.yaml")
+        feats = torch.from_numpy(synth.activations(3000, 384, seed=1, stream=0, bf16=False))
+        FeatureCache(cfg.data.cache_dir / "features", WhisperConfig(), cfg.data).save(feats, "encoder", 0, num_samples=2)
+        spec = importlib.util.spec_from_file_location("wsae_train_cli", str(GOLDEN_ROOT / "scripts" / "train.py"))
+        cli = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(cli)
+        cli.main(["--config", str(tmp_path / "cfg.yaml"), "--layer", "encoder:0", "--no-wandb"])
+        run = tmp_path / "out" / "e2e_encoder_layer0"
+        assert (run / "sae_final.pt").exists() and (run / "final.pt").exists() and (run / "checkpoint_epoch2.pt").exists()
+        rows = json.loads((run / "metrics.json").read_text())
+        assert len(rows) == 3 * 47 and rows[-1]["step"] == 141  # ceil(3000/64) = 47 steps per epoch
+        first = np.mean([r["loss"] for r in rows[:47]])
+        last = np.mean([r["loss"] for r in rows[-47:]])
+        assert last < first  # ref test_training.py:214-240
+        assert all(r["l0"] <= 32.0 for r in rows)
+        sd = torch.load(run / "sae_final.pt", weights_only=True)
+        assert sd["decoder.weight"].shape == (384, 3072) and sd["feature_last_activated"].dtype == torch.int64
+        assert int(sd["step_count"]) == 141
