@@ -91,6 +91,9 @@ int wsae_param_offsets(int32_t input_dim, int32_t hidden_dim, int64_t offsets[5]
 /* ctx: dims + mode + all workspace (bf16 weight shadows, TopK scratch, partial-sum slabs). */
 int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out);
 int wsae_ctx_destroy(wsae_ctx* ctx);
+/* Debug/test switch: 1 = wsae_encode_topk always materialises the dense [B,H] pre-activations and
+ * runs the standalone TopK kernel, 0 (default) = fused filter path where the shape qualifies. */
+int wsae_ctx_set_dense_topk(wsae_ctx* ctx, int32_t on);
 size_t wsae_ctx_workspace_bytes(const wsae_ctx* ctx);
 
 /* Refresh what the kernels derive from the master weights: bf16 shadow of W_e and the folded
@@ -231,7 +234,9 @@ int wsae_ring_fill_synthetic(wsae_ring* ring, uint64_t seed, int64_t n_rows, voi
 #define WSAE_K_MEMSET 13
 #define WSAE_K_WGRAD_REDUCE 14
 #define WSAE_K_BUCKET 15
-#define WSAE_K_COUNT 16
+#define WSAE_K_ENCODE_FILTER 16
+#define WSAE_K_SELECT 17
+#define WSAE_K_COUNT 18
 const char* wsae_kernel_name(int32_t kernel_id);
 int wsae_profile_enable(wsae_ctx* ctx, int32_t kernel_id, int32_t max_samples);
 int wsae_profile_disable(wsae_ctx* ctx);

@@ -92,6 +92,14 @@ struct wsae_ctx {
     int32_t* counters;    // small int scratch (fallback rows, dead count, resample cursors)
     int32_t* dead_list;   // [H] compacted dead feature indices (resample)
     int32_t* row_order;   // [maxB] rows sorted by error (resample)
+    // ---- fused TopK (filter path) ---------------------------------------------------------------
+    float* thr_vals;      // [maxB][64] sample-pass TopK values (the last one is the row threshold)
+    int32_t* thr_idx;     // [maxB][64]
+    uint64_t* cand;       // [maxB][ceil(H/128)][CAND_SLOTS] candidate keys
+    int32_t* cand_cnt;    // [maxB][ceil(H/128)]
+    int32_t* cand_ovf;    // [maxB] slot-group overflow flags
+    int32_t* flag_rows;   // [maxB] rows sent to the exact fallback
+    int force_dense_topk; // tests: take the dense two-kernel path regardless of shape
     int n_dec_blocks;     // blocks used by the last decode launch (partials to reduce)
     int n_sq_parts;       // global-norm partials left in part_sq by the last wsae_weight_grads
     float* dbd2;          // [64][D] level-1 reduction of part_dbd

@@ -90,6 +90,13 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     const size_t o_eh = cv.take((size_t)maxB * K * 4);
     const size_t o_ed = cv.take((size_t)maxB * K * 4);
     const size_t o_eo = cv.take((size_t)((maxB + 31) / 32) * ((H + 127) / 128 + 1) * 4);
+    const size_t ntile = (size_t)(H + 127) / 128;
+    const size_t o_tv = cv.take((size_t)maxB * 64 * 4);
+    const size_t o_ti = cv.take((size_t)maxB * 64 * 4);
+    const size_t o_cd = cv.take((size_t)maxB * ntile * 24 * 8);
+    const size_t o_cc = cv.take((size_t)maxB * ntile * 4);
+    const size_t o_co = cv.take((size_t)maxB * 4);
+    const size_t o_fr = cv.take((size_t)maxB * 4);
     const size_t o_dl = cv.take((size_t)H * 4);
     const size_t o_ro = cv.take((size_t)maxB * 4);
     char* base = nullptr;
@@ -128,6 +135,12 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     c->ent_hid = base + o_eh;
     c->ent_dpre = base + o_ed;
     c->ent_off = (int32_t*)(base + o_eo);
+    c->thr_vals = (float*)(base + o_tv);
+    c->thr_idx = (int32_t*)(base + o_ti);
+    c->cand = (uint64_t*)(base + o_cd);
+    c->cand_cnt = (int32_t*)(base + o_cc);
+    c->cand_ovf = (int32_t*)(base + o_co);
+    c->flag_rows = (int32_t*)(base + o_fr);
     c->dead_list = (int32_t*)(base + o_dl);
     c->row_order = (int32_t*)(base + o_ro);
     c->ws_bytes = cv.total;
@@ -146,7 +159,7 @@ extern "C" int wsae_ctx_destroy(wsae_ctx* ctx) {
 // ---- kernel timing -------------------------------------------------------------------------------
 static const char* const k_names[WSAE_K_COUNT] = {
     "stage_batch", "encode_gemm", "topk", "decode", "decode_finalize", "transpose_g", "wgrad",
-    "bias_grads", "sqnorm", "adamw", "rownorm", "prepare", "dead_scan", "memset", "wgrad_reduce", "bucket"};
+    "bias_grads", "sqnorm", "adamw", "rownorm", "prepare", "dead_scan", "memset", "wgrad_reduce", "bucket", "encode_filter", "select"};
 
 extern "C" const char* wsae_kernel_name(int32_t id) { return (id >= 0 && id < WSAE_K_COUNT) ? k_names[id] : "?"; }
 
@@ -203,6 +216,12 @@ extern "C" int wsae_profile_read(wsae_ctx* ctx, int32_t kernel_id, int32_t* n_la
     }
     *n_launches = n;
     *total_ms = tot;
+    return WSAE_OK;
+}
+
+extern "C" int wsae_ctx_set_dense_topk(wsae_ctx* ctx, int32_t on) {
+    WSAE_REQUIRE(ctx, "wsae_ctx_set_dense_topk: null ctx");
+    ctx->force_dense_topk = on ? 1 : 0;
     return WSAE_OK;
 }
 

@@ -3,6 +3,20 @@
 #include "wsae_common.h"
 #include "wsae_mfma.h"
 
+__device__ __forceinline__ uint32_t f32_ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_f32(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, m, 64);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // stage_batch: gather + convert the batch once.
 //   xb [B][D]      compute dtype: bf16(x) (BF16 mode) or x - b_pre in f32 (FP32 mode, model.py:108)
@@ -71,18 +85,37 @@ __global__ void __launch_bounds__(256) stage_batch_kernel(const void* __restrict
 
 // ------------------------------------------------------------------------------------------------
 // pre[b][h] = sum_d xb[b][d] * W[h][d] + bias[h]          (model.py:111)
+//
+// One kernel, three uses (template MODE):
+//   GEMM_DENSE  : write the [B][ldp] pre-activation matrix (API path, small shapes, sample pass, fallback)
+//   GEMM_FILTER : do NOT write pre; keep only elements >= thr[b] as 64-bit keys in a private
+//                 (row, feature-tile) slot group -- the fused-TopK path.  thr[b] comes from a sample
+//                 pass (every wstride-th feature), so the [B,H] matrix never goes to HBM.
+// wstride > 1 samples features h = n * wstride (W row stride and bias index scale with it).
+// arows / n_dev (nullable): batch-row indirection and device-side row count, used by the fallback
+// launch over the rows the filter could not settle; blocks beyond the count exit immediately.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) encode_gemm_kernel(const T* __restrict__ xb, const T* __restrict__ W,
-                                                          const float* __restrict__ bias, float* __restrict__ pre,
-                                                          int B, int H, int D) {
+#define GEMM_DENSE 0
+#define GEMM_FILTER 1
+#define CAND_SLOTS 24  // candidate slots per (row, 128-feature tile)
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256)
+encode_gemm_kernel(const T* __restrict__ xb, const T* __restrict__ W, const float* __restrict__ bias,
+                   float* __restrict__ pre, int ldp, int B, int H, int D, int wstride, const int32_t* __restrict__ arows,
+                   const int32_t* __restrict__ n_dev, const float* __restrict__ thr, int thr_stride,
+                   uint64_t* __restrict__ cand, int32_t* __restrict__ cand_cnt, int32_t* __restrict__ ovf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
     char* Bs = smem + TILE_LDS_BYTES;
+    int* cnt_s = (int*)(smem + 2 * TILE_LDS_BYTES);  // [128] (FILTER)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * TILE_M, n0 = blockIdx.x * TILE_N;
+    if (n_dev) B = min(B, *n_dev);
+    if (m0 >= B) return;
     constexpr int KT = Mfma<T>::KT;
+    if (MODE == GEMM_FILTER && tid < 128) cnt_s[tid] = 0;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -92,35 +125,90 @@ __global__ void __launch_bounds__(256) encode_gemm_kernel(const T* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // A rows may be indirect (fallback): resolve this thread's four slab rows once
+    int arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + ((tid + 256 * i) >> 3);
+        arow[i] = row < B ? (arows ? arows[row] : row) : -1;
+    }
+    constexpr int EPC = 16 / (int)sizeof(T);
+    auto load_a = [&](SlabRegs<T>& r, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ((tid + 256 * i) & 7) * EPC;
+            r.v[i] = (arow[i] >= 0 && k < D) ? *(const uint4*)(xb + (int64_t)arow[i] * D + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    const int64_t ldw = (int64_t)D * wstride;
     SlabRegs<T> ra, rb;
-    slab_load<T>(ra, xb, D, m0, B, 0, D, tid);
-    slab_load<T>(rb, W, D, n0, H, 0, D, tid);
+    load_a(ra, 0);
+    slab_load<T>(rb, W, ldw, n0, H, 0, D, tid);
     const int nk = (D + KT - 1) / KT;
     for (int kt = 0; kt < nk; ++kt) {
         slab_store<T>(ra, As, tid);
         slab_store<T>(rb, Bs, tid);
         __syncthreads();
         if (kt + 1 < nk) {
-            slab_load<T>(ra, xb, D, m0, B, (kt + 1) * KT, D, tid);
-            slab_load<T>(rb, W, D, n0, H, (kt + 1) * KT, D, tid);
+            load_a(ra, (kt + 1) * KT);
+            slab_load<T>(rb, W, ldw, n0, H, (kt + 1) * KT, D, tid);
         }
         Mfma<T>::slab(As, Bs, wm * 64, wn * 64, lane, acc);
         __syncthreads();
     }
     const int col = lane & 31, rq = lane >> 5;
+    if (MODE == GEMM_DENSE) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int h = n0 + wn * 64 + ni * 32 + col;
-            if (h >= H) continue;
-            const float bv = bias[h];
+            for (int ni = 0; ni < 2; ++ni) {
+                const int h = n0 + wn * 64 + ni * 32 + col;
+                if (h >= H) continue;
+                const float bv = bias[(int64_t)h * wstride];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int b = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                    if (b < B) pre[(int64_t)b * ldp + h] = acc[mi][ni][r] + bv;
+                }
+            }
+    } else {
+        const int ntile = gridDim.x;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            float tv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int b = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-                if (b < B) pre[(int64_t)b * H + h] = acc[mi][ni][r] + bv;
+                tv[r] = b < B ? thr[(int64_t)b * thr_stride] : INFINITY;
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int h = n0 + wn * 64 + ni * 32 + col;
+                const bool hin = h < H;
+                const float bv = hin ? bias[h] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[mi][ni][r] + bv;
+                    const bool pass = hin && v >= tv[r];
+                    if (__ballot(pass)) {  // wave-uniform: most registers hold no candidate at all
+                        if (pass) {
+                            const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                            const int slot = atomicAdd(&cnt_s[rl], 1);
+                            if (slot < CAND_SLOTS)
+                                cand[((int64_t)(m0 + rl) * ntile + blockIdx.x) * CAND_SLOTS + slot] =
+                                    ((uint64_t)f32_ord(v) << 32) | (uint32_t)(~(uint32_t)h);
+                        }
+                    }
+                }
             }
         }
+        __syncthreads();
+        if (tid < 128 && m0 + tid < B) {
+            const int c = cnt_s[tid];
+            cand_cnt[(int64_t)(m0 + tid) * ntile + blockIdx.x] = min(c, CAND_SLOTS);
+            if (c > CAND_SLOTS) ovf[m0 + tid] = 1;  // slot group overflowed: the row goes to the exact fallback
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -134,19 +222,6 @@ __global__ void __launch_bounds__(256) encode_gemm_kernel(const T* __restrict__ 
 //   Rows with more than 256 candidates (heavy ties, adversarial layouts) or K > 64 take the exact
 //   path: bisection on the 64-bit key for the K-th largest key, then the same compaction + sort.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t f32_ord(float f) {
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord_f32(uint32_t o) {
-    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
-}
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, m, 64);
-    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-
 template <int NPL>
 __device__ __forceinline__ void wave_sort_desc(uint64_t (&key)[NPL], int lane) {
 #pragma unroll
@@ -250,11 +325,14 @@ __device__ __forceinline__ int topk_count_ge(const float* __restrict__ row, int 
 
 __global__ void __launch_bounds__(256) topk_kernel(const float* __restrict__ pre, int B, int H, int K,
                                                    float* __restrict__ vals, int32_t* __restrict__ idx,
-                                                   int64_t* __restrict__ step_count, int32_t* __restrict__ fallback_rows) {
+                                                   int64_t* __restrict__ step_count, int32_t* __restrict__ fallback_rows,
+                                                   const int32_t* __restrict__ out_rows,
+                                                   const int32_t* __restrict__ n_dev) {
     __shared__ uint64_t lists[4][TOPK_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (blockIdx.x == 0 && threadIdx.x == 0 && step_count) *step_count += 1;  // model.py:175
     const int b = blockIdx.x * 4 + wave;
+    if (n_dev) B = min(B, *n_dev);
     if (b >= B) return;
     const float* row = pre + (int64_t)b * H;
     uint64_t* list = lists[wave];
@@ -285,14 +363,68 @@ __global__ void __launch_bounds__(256) topk_kernel(const float* __restrict__ pre
         }
         count = topk_compact(row, H, prefix, list, lane);  // == K exactly (keys are distinct)
     }
-    float* vrow = vals + (int64_t)b * K;
-    int32_t* irow = idx + (int64_t)b * K;
+    const int ob = out_rows ? out_rows[b] : b;  // fallback launches write back to the original row
+    float* vrow = vals + (int64_t)ob * K;
+    int32_t* irow = idx + (int64_t)ob * K;
     if (count <= 64)
         topk_emit<1>(list, count, K, lane, vrow, irow);
     else if (count <= 128)
         topk_emit<2>(list, count, K, lane, vrow, irow);
     else
         topk_emit<4>(list, count, K, lane, vrow, irow);
+}
+
+// ------------------------------------------------------------------------------------------------
+// select_kernel: final TopK of the fused path.  One wave per row gathers the row's candidates from its
+// per-tile slot groups (lanes over tiles, ballot-free prefix via wave scan), and if they are a
+// complete answer (>= K candidates, no slot group overflowed, <= TOPK_CAP in total) sorts them and
+// emits the K best.  Otherwise the row is appended to flag_rows for the exact fallback launch.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+select_kernel(const uint64_t* __restrict__ cand, const int32_t* __restrict__ cand_cnt, int32_t* __restrict__ ovf, int B,
+              int ntile, int K, float* __restrict__ vals, int32_t* __restrict__ idx, int32_t* __restrict__ flag_rows,
+              int32_t* __restrict__ n_flag, int64_t* __restrict__ step_count) {
+    __shared__ uint64_t lists[4][TOPK_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && step_count) *step_count += 1;  // model.py:175
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    uint64_t* list = lists[wave];
+    int total = 0;
+    bool bad = ovf[b] != 0;
+    if (bad && lane == 0) ovf[b] = 0;
+    for (int t0 = 0; t0 < ntile && !bad; t0 += 64) {
+        const int t = t0 + lane;
+        const int c = t < ntile ? cand_cnt[(int64_t)b * ntile + t] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += n;
+        }
+        const int off = total + incl - c;
+        const int sum = __shfl(incl, 63, 64);
+        if (total + sum > TOPK_CAP) {
+            bad = true;
+            break;
+        }
+        const uint64_t* src = cand + ((int64_t)b * ntile + t) * CAND_SLOTS;
+        for (int s_ = 0; s_ < c; ++s_) list[off + s_] = src[s_];
+        total += sum;
+    }
+    if (bad || total < K) {
+        if (lane == 0) flag_rows[atomicAdd(n_flag, 1)] = b;
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* vrow = vals + (int64_t)b * K;
+    int32_t* irow = idx + (int64_t)b * K;
+    if (total <= 64)
+        topk_emit<1>(list, total, K, lane, vrow, irow);
+    else if (total <= 128)
+        topk_emit<2>(list, total, K, lane, vrow, irow);
+    else
+        topk_emit<4>(list, total, K, lane, vrow, irow);
 }
 
 // hidden = zeros; hidden[b][idx] = relu(val)        (model.py:115-116)
@@ -305,15 +437,24 @@ __global__ void __launch_bounds__(256) densify_kernel(const float* __restrict__ 
     hidden[(int64_t)b * H + idx[i]] = v > 0.f ? v : 0.f;
 }
 
+// fold the number of fallback rows into the stats counter and clear it for the next call
+__global__ void flag_reset_kernel(int32_t* __restrict__ n_flag, int32_t* __restrict__ fb) {
+    if (threadIdx.x == 0) {
+        const int n = *n_flag;
+        if (n) *fb += n;
+        *n_flag = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 template <typename T>
-static int stage_and_gemm(wsae_ctx* c, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,
-                          float* pre, hipStream_t st) {
-    const int D = c->D, H = c->H;
+static int stage_batch(wsae_ctx* c, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,
+                       hipStream_t st) {
+    const int D = c->D;
     const int ldT = round_up(B, 128);
     dim3 sg(ceil_div(ldT, 64), ceil_div(D, 64));
     WSAE_PROF_BEGIN(c, WSAE_K_STAGE_BATCH, st);
@@ -323,12 +464,70 @@ static int stage_and_gemm(wsae_ctx* c, const float* params, const void* x, int x
         stage_batch_kernel<WSAE_DT_BF16, T><<<sg, 256, 0, st>>>(x, rows, params + c->off[4], (T*)c->xb, (T*)c->xT, B, D, ldT);
     WSAE_PROF_END(c, WSAE_K_STAGE_BATCH, st);
     WSAE_LAUNCH_CHECK();
+    return WSAE_OK;
+}
+
+template <typename T>
+static int gemm_dense(wsae_ctx* c, const float* params, int B, int nfeat, int wstride, float* pre, int ldp,
+                      const int32_t* arows, const int32_t* n_dev, hipStream_t st) {
     const T* W = sizeof(T) == 2 ? (const T*)c->We_bf16 : (const T*)(params + c->off[0]);
     const float* bias = sizeof(T) == 2 ? c->c_fold : params + c->off[2];
-    dim3 gg(ceil_div(H, TILE_N), ceil_div(B, TILE_M));
+    dim3 gg(ceil_div(nfeat, TILE_N), ceil_div(B, TILE_M));
     WSAE_PROF_BEGIN(c, WSAE_K_ENCODE_GEMM, st);
-    encode_gemm_kernel<T><<<gg, 256, 2 * TILE_LDS_BYTES, st>>>((const T*)c->xb, W, bias, pre, B, H, D);
+    encode_gemm_kernel<T, GEMM_DENSE><<<gg, 256, 2 * TILE_LDS_BYTES, st>>>(
+        (const T*)c->xb, W, bias, pre, ldp, B, nfeat, c->D, wstride, arows, n_dev, nullptr, 0, nullptr, nullptr, nullptr);
     WSAE_PROF_END(c, WSAE_K_ENCODE_GEMM, st);
+    WSAE_LAUNCH_CHECK();
+    return WSAE_OK;
+}
+
+template <typename T>
+static int stage_and_gemm(wsae_ctx* c, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,
+                          float* pre, hipStream_t st) {
+    int rc = stage_batch<T>(c, params, x, x_dtype, rows, B, st);
+    if (rc) return rc;
+    return gemm_dense<T>(c, params, B, c->H, 1, pre, c->H, nullptr, nullptr, st);
+}
+
+// Fused-TopK path: sample pass -> per-row threshold -> filtering GEMM -> select -> exact fallback
+// for the (rare) rows the filter could not settle.  Never writes the [B,H] pre-activation matrix.
+//   sample: every 8th feature, S = H/8 of them; thr[b] = KS-th largest sample pre-activation with
+//   KS = ceil(3*K/8): the expected rank of thr[b] in the full row is ~3K, so ~3K candidates survive
+//   the filter and a row falls short of K candidates with probability ~1e-3.  Correctness never
+//   depends on these odds: a row with < K candidates (or an overflowed slot group) is recomputed exactly.
+template <typename T>
+static int encode_topk_fused(wsae_ctx* c, const float* params, int B, float* vals, int32_t* idx, int64_t* step_count,
+                             int32_t* fb, hipStream_t st) {
+    const int H = c->H, K = c->K, D = c->D;
+    const int S = H / 8, KS = max(4, (3 * K + 7) / 8);
+    int rc = gemm_dense<T>(c, params, B, S, 8, c->pre, S, nullptr, nullptr, st);
+    if (rc) return rc;
+    WSAE_PROF_BEGIN(c, WSAE_K_TOPK, st);
+    topk_kernel<<<ceil_div(B, 4), 256, 0, st>>>(c->pre, B, S, KS, c->thr_vals, c->thr_idx, nullptr, fb, nullptr, nullptr);
+    WSAE_PROF_END(c, WSAE_K_TOPK, st);
+    WSAE_LAUNCH_CHECK();
+    const T* W = sizeof(T) == 2 ? (const T*)c->We_bf16 : (const T*)(params + c->off[0]);
+    const float* bias = sizeof(T) == 2 ? c->c_fold : params + c->off[2];
+    const int ntile = ceil_div(H, TILE_N);
+    dim3 gg(ntile, ceil_div(B, TILE_M));
+    WSAE_PROF_BEGIN(c, WSAE_K_ENCODE_FILTER, st);
+    encode_gemm_kernel<T, GEMM_FILTER><<<gg, 256, 2 * TILE_LDS_BYTES + 512, st>>>(
+        (const T*)c->xb, W, bias, nullptr, 0, B, H, D, 1, nullptr, nullptr, c->thr_vals + (KS - 1), KS, c->cand,
+        c->cand_cnt, c->cand_ovf);
+    WSAE_PROF_END(c, WSAE_K_ENCODE_FILTER, st);
+    WSAE_LAUNCH_CHECK();
+    int32_t* n_flag = c->counters + 8;
+    WSAE_PROF_BEGIN(c, WSAE_K_SELECT, st);
+    select_kernel<<<ceil_div(B, 4), 256, 0, st>>>(c->cand, c->cand_cnt, c->cand_ovf, B, ntile, K, vals, idx, c->flag_rows,
+                                                  n_flag, step_count);
+    WSAE_PROF_END(c, WSAE_K_SELECT, st);
+    WSAE_LAUNCH_CHECK();
+    // exact fallback over the flagged rows (device-side count; blocks beyond it exit at once)
+    rc = gemm_dense<T>(c, params, B, H, 1, c->pre, H, c->flag_rows, n_flag, st);
+    if (rc) return rc;
+    topk_kernel<<<ceil_div(B, 4), 256, 0, st>>>(c->pre, B, H, K, vals, idx, nullptr, fb, c->flag_rows, n_flag);
+    WSAE_LAUNCH_CHECK();
+    flag_reset_kernel<<<1, 64, 0, st>>>(n_flag, fb);
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;
 }
@@ -357,12 +556,21 @@ extern "C" int wsae_encode_topk(wsae_ctx* ctx, const float* params, const void* 
     if (rc) return rc;
     WSAE_REQUIRE(params && vals && idx, "wsae_encode_topk: null argument");
     hipStream_t st = (hipStream_t)stream;
+    int32_t* fb = stats ? &stats->topk_fallback_rows : ctx->counters;
+    // fused TopK pays once the [B,H] round trip dominates; small shapes keep the dense two-kernel path
+    const bool fused = ctx->H >= 1024 && ctx->H % 128 == 0 && ctx->K <= 64 && B >= 512 && !ctx->force_dense_topk;
+    if (fused) {
+        rc = ctx->prec == WSAE_PREC_BF16 ? stage_batch<bf16_t>(ctx, params, x, x_dtype, rows, B, st)
+                                         : stage_batch<float>(ctx, params, x, x_dtype, rows, B, st);
+        if (rc) return rc;
+        return ctx->prec == WSAE_PREC_BF16 ? encode_topk_fused<bf16_t>(ctx, params, B, vals, idx, step_count, fb, st)
+                                           : encode_topk_fused<float>(ctx, params, B, vals, idx, step_count, fb, st);
+    }
     rc = ctx->prec == WSAE_PREC_BF16 ? stage_and_gemm<bf16_t>(ctx, params, x, x_dtype, rows, B, ctx->pre, st)
                                      : stage_and_gemm<float>(ctx, params, x, x_dtype, rows, B, ctx->pre, st);
     if (rc) return rc;
-    int32_t* fb = stats ? &stats->topk_fallback_rows : ctx->counters;
     WSAE_PROF_BEGIN(ctx, WSAE_K_TOPK, st);
-    topk_kernel<<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb);
+    topk_kernel<<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb, nullptr, nullptr);
     WSAE_PROF_END(ctx, WSAE_K_TOPK, st);
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;

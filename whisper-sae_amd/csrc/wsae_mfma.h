@@ -27,9 +27,15 @@ template <>
 struct Mfma<bf16_t> {
     static constexpr int KT = 64;  // elements per K slab
     // acc[mi][ni] += A(64 rows at a_row0) x Bt(64 rows at b_row0) over the whole slab
+    // ROWSUM: additionally rs[mi] += A(mi) x ones, i.e. every column of rs[mi] holds the row sums of
+    // the A slice (exact fp32 accumulation in fixed order; used for db_e = sum_b dpre)
+    template <bool ROWSUM = false>
     static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
-                                                f32x16 (&acc)[2][2]) {
+                                                f32x16 (&acc)[2][2], f32x16* rs = nullptr) {
         const int r = lane & 31, h = lane >> 5;
+        bf16x8 ones;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             bf16x8 a[2], b[2];
@@ -43,6 +49,11 @@ struct Mfma<bf16_t> {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            if (ROWSUM) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    rs[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], ones, rs[mi], 0, 0, 0);
+            }
         }
     }
 };
@@ -50,8 +61,9 @@ struct Mfma<bf16_t> {
 template <>
 struct Mfma<float> {
     static constexpr int KT = 32;
+    template <bool ROWSUM = false>
     static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
-                                                f32x16 (&acc)[2][2]) {
+                                                f32x16 (&acc)[2][2], f32x16* rs = nullptr) {
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
@@ -66,6 +78,11 @@ struct Mfma<float> {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            if (ROWSUM) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    rs[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], 1.0f, rs[mi], 0, 0, 0);
+            }
         }
     }
 };

@@ -83,25 +83,30 @@ bucket_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, c
 // k-1 (all reads of buffer k&1 belong to chunk k-2), and the operands of chunk k+1 are fetched into
 // registers while the MFMAs of chunk k run.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256)
+// NT = 128-column groups per workgroup: the workgroup has 4*NT waves, wave group g works on columns
+// [d0 + 128 g, d0 + 128 (g+1)) against the SAME sparse slice, so one zero+scatter feeds NT times the MFMA work.
+template <typename T, int NT>
+__global__ void __launch_bounds__(256 * NT)
 wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid, const T* __restrict__ ent_dpre,
              const int32_t* __restrict__ ent_off, const T* __restrict__ xT, const T* __restrict__ gT, int B, int ldT,
              int H, int D, int nsplit, int ntm, int ntn, float* __restrict__ out, int64_t slab_stride,
              float* __restrict__ dbe_slab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTHR = 256 * NT;
+    constexpr int STAGE = (1 + NT) * TILE_LDS_BYTES;  // A slice + NT dense slabs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = wave >> 2, gtid = tid & 255;      // column group, thread index inside it
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int split = blockIdx.x % nsplit;
     int tile = blockIdx.x / nsplit;
     const int which = tile / (ntm * ntn);  // 0: dW_dT (hidden, g)   1: dW_e (dpre, x_c)
     tile -= which * ntm * ntn;
     const int tm = tile / ntn;
-    const int f0 = tm * TILE_M, d0 = (tile % ntn) * TILE_N;
+    const int f0 = tm * TILE_M, d0 = (tile % ntn) * TILE_N * NT + grp * TILE_N;
     constexpr int KT = Mfma<T>::KT;
     const T* Bt = which == 0 ? gT : xT;
     const T* sv = which == 0 ? ent_hid : ent_dpre;
-    const bool do_dbe = (which == 1) && (d0 == 0);
+    const bool do_dbe = (which == 1) && (tile % ntn == 0);
 
     const int nchunks = (B + KT - 1) / KT;
     const int per = (nchunks + nsplit - 1) / nsplit;
@@ -114,46 +119,60 @@ wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float dbe_acc = 0.f;  // thread t < 128 owns feature row f0 + t
+    // db_e = row sums of the dpre slice: the waves of column group 0 / wn 0 run one extra MFMA against a
+    // ones operand per A fragment (fixed summation order, no LDS re-read, no atomics)
+    const bool rs_wave = do_dbe && grp == 0 && wn == 0;
+    f32x16 rs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs[i][r] = 0.f;
 
     SlabRegs<T> rb;
     int e_lo = 0, e_n = 0;   // entry range of the chunk whose operands sit in registers
-    uint32_t e_pos = 0;      // first 256 entries: one per thread
+    int n_lo = 0, n_n = 0;   // ... and of the chunk after it (offsets run one chunk ahead of the entries)
+    uint32_t e_pos = 0;      // first NTHR entries: one per thread
     T e_val = (T)0.f;
-    auto fetch = [&](int ck) {
-        slab_load<T>(rb, Bt, ldT, d0, D, ck * KT, ldT, tid);
-        const int32_t* o = ent_off + (int64_t)ck * (ntm + 1) + tm;
-        e_lo = o[0];
-        e_n = o[1] - e_lo;
+    auto offsets = [&](int ck) {
+        if (ck < c_end) {
+            const int32_t* o = ent_off + (int64_t)ck * (ntm + 1) + tm;
+            n_lo = o[0];
+            n_n = o[1] - n_lo;
+        }
+    };
+    auto fetch = [&](int ck) {  // entry range of ck must already sit in (n_lo, n_n)
+        slab_load<T>(rb, Bt, ldT, d0, D, ck * KT, ldT, gtid);
+        e_lo = n_lo;
+        e_n = n_n;
         if (tid < e_n) {
             e_pos = ent_pos[e_lo + tid];
             e_val = sv[e_lo + tid];
         }
+        offsets(ck + 1);
     };
-    if (c_begin < c_end) fetch(c_begin);
+    if (c_begin < c_end) {
+        offsets(c_begin);
+        fetch(c_begin);
+    }
     for (int ck = c_begin; ck < c_end; ++ck) {
         const int buf = (ck - c_begin) & 1;
-        char* As = smem + buf * 2 * TILE_LDS_BYTES;
-        char* Bs = As + TILE_LDS_BYTES;
-        for (int c = tid; c < TILE_LDS_BYTES / 16; c += 256) *(uint4*)(As + c * 16) = make_uint4(0, 0, 0, 0);
-        slab_store<T>(rb, Bs, tid);
+        char* As = smem + buf * STAGE;
+        char* Bs = As + (1 + grp) * TILE_LDS_BYTES;
+        for (int c = tid; c < TILE_LDS_BYTES / 16; c += NTHR) *(uint4*)(As + c * 16) = make_uint4(0, 0, 0, 0);
+        slab_store<T>(rb, Bs, gtid);
         __syncthreads();
         const int n = e_n, lo = e_lo;
         if (tid < n) *(T*)(As + (e_pos >> 16) * LDS_ROW_BYTES + (e_pos & 0xFFFFu) * (int)sizeof(T)) = e_val;
-        for (int e = tid + 256; e < n; e += 256) {  // buckets beyond 256 entries (rare)
+        for (int e = tid + NTHR; e < n; e += NTHR) {  // buckets beyond one entry per thread (rare)
             const uint32_t p = ent_pos[lo + e];
             *(T*)(As + (p >> 16) * LDS_ROW_BYTES + (p & 0xFFFFu) * (int)sizeof(T)) = sv[lo + e];
         }
         if (ck + 1 < c_end) fetch(ck + 1);  // next chunk's operands fly during the MFMAs
         __syncthreads();
-        if (do_dbe && tid < 128) {  // db_e: row sums of the slice, fixed order
-            const T* row = (const T*)(As + tid * LDS_ROW_BYTES);
-            float s = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < KT; ++k) s += (float)row[k];
-            dbe_acc += s;
-        }
-        Mfma<T>::slab(As, Bs, wm * 64, wn * 64, lane, acc);
+        if (rs_wave)
+            Mfma<T>::template slab<true>(As, Bs, wm * 64, wn * 64, lane, acc, rs);
+        else
+            Mfma<T>::template slab<false>(As, Bs, wm * 64, wn * 64, lane, acc);
     }
 
     float* dst = out + (int64_t)split * slab_stride + (which == 0 ? (int64_t)H * D : 0);
@@ -170,7 +189,15 @@ wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid
                 if (f < H) dst[(int64_t)f * D + d] = acc[mi][ni][r];
             }
         }
-    if (do_dbe && tid < 128 && f0 + tid < H) dbe_slab[(int64_t)split * H + f0 + tid] = dbe_acc;
+    if (rs_wave && col == 0) {  // column 0 of the ones product = the row sums
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = f0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                if (f < H) dbe_slab[(int64_t)split * H + f] = rs[mi][r];
+            }
+    }
 }
 
 // grads[W parts] = sum over splits of the slabs (fixed order); db_e likewise; in BF16 mode the
@@ -295,7 +322,7 @@ __global__ void __launch_bounds__(256) bias_finish_kernel(const float* __restric
 }
 
 template <typename T>
-static void launch_wgrad(wsae_ctx* ctx, dim3 grid, size_t sh, hipStream_t st, const float* vals, const int32_t* idx,
+static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const float* vals, const int32_t* idx,
                          const float* dpre, int B, int ldT, int nsplit, int ntm, int ntn, float* out,
                          int64_t slab_stride) {
     constexpr int KT = Mfma<T>::KT;
@@ -305,9 +332,12 @@ static void launch_wgrad(wsae_ctx* ctx, dim3 grid, size_t sh, hipStream_t st, co
                                               (T*)ctx->ent_dpre, ctx->ent_off);
     WSAE_PROF_END(ctx, WSAE_K_BUCKET, st);
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD, st);
-    wgrad_kernel<T><<<grid, 256, sh, st>>>(ctx->ent_pos, (const T*)ctx->ent_hid, (const T*)ctx->ent_dpre, ctx->ent_off,
-                                           (const T*)ctx->xT, (const T*)ctx->gT, B, ldT, ctx->H, ctx->D, nsplit, ntm, ntn,
-                                           out, slab_stride, ctx->dbe_slab);
+#define WG_ARGS ctx->ent_pos, (const T*)ctx->ent_hid, (const T*)ctx->ent_dpre, ctx->ent_off, (const T*)ctx->xT, \
+                (const T*)ctx->gT, B, ldT, ctx->H, ctx->D, nsplit, ntm, ntn, out, slab_stride, ctx->dbe_slab
+    if (nt == 3) wgrad_kernel<T, 3><<<grid, 768, 2 * 4 * TILE_LDS_BYTES, st>>>(WG_ARGS);
+    else if (nt == 2) wgrad_kernel<T, 2><<<grid, 512, 2 * 3 * TILE_LDS_BYTES, st>>>(WG_ARGS);
+    else wgrad_kernel<T, 1><<<grid, 256, 2 * 2 * TILE_LDS_BYTES, st>>>(WG_ARGS);
+#undef WG_ARGS
     WSAE_PROF_END(ctx, WSAE_K_WGRAD, st);
 }
 
@@ -322,17 +352,19 @@ extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void*
     const int ldT = (B + 127) / 128 * 128;
     const int kt = ctx->prec == WSAE_PREC_BF16 ? 64 : 32;
     const int nchunks = ceil_div(B, kt);
-    const int ntm = ceil_div(H, TILE_M), ntn = ceil_div(D, TILE_N);
+    // column groups per workgroup: all of D in one workgroup when D is 2 or 3 tiles wide
+    const int ncol = ceil_div(D, TILE_N);
+    const int nt = (ncol % 3 == 0) ? 3 : (ncol % 2 == 0) ? 2 : 1;
+    const int ntm = ceil_div(H, TILE_M), ntn = ncol / nt;
     const int nsplit = min(WSAE_WGRAD_MAX_SPLIT, max(1, nchunks / 4));  // >= 4 chunks per split; 8 = one per XCD
     const int64_t slab_stride = 2 * (int64_t)H * D;
     WSAE_REQUIRE(ntm <= BUCKET_MAX_TILES, "hidden_dim %d too large for the bucket pass (max %d)", H, BUCKET_MAX_TILES * 128);
     dim3 grid(ntm * ntn * 2 * nsplit);
-    const size_t sh = 4 * TILE_LDS_BYTES;
     float* out = ctx->wg_slabs;
     if (ctx->prec == WSAE_PREC_BF16)
-        launch_wgrad<bf16_t>(ctx, grid, sh, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride);
+        launch_wgrad<bf16_t>(ctx, grid, nt, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride);
     else
-        launch_wgrad<float>(ctx, grid, sh, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride);
+        launch_wgrad<float>(ctx, grid, nt, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride);
     WSAE_LAUNCH_CHECK();
 
     float* dbe = grads + ctx->off[2];

@@ -48,6 +48,7 @@ SIGNATURES = {
     "wsae_ctx_create": (C.c_int, [C.POINTER(Config), C.POINTER(_p)]),
     "wsae_ctx_destroy": (C.c_int, [_p]),
     "wsae_ctx_workspace_bytes": (C.c_size_t, [_p]),
+    "wsae_ctx_set_dense_topk": (C.c_int, [_p, _i32]),
     "wsae_prepare": (C.c_int, [_p, _p, _p]),
     "wsae_encode_topk": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
     "wsae_encode_dense": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p]),
@@ -144,7 +145,7 @@ def pack_layout(input_dim: int, hidden_dim: int) -> tuple:
     return 2 * d * h + h + 2 * d, off
 
 
-KERNEL_COUNT = 16
+KERNEL_COUNT = 18
 
 
 def profile_read(handle: int) -> dict:
