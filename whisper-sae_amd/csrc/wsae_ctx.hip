@@ -1,5 +1,6 @@
 // ctx lifecycle, error reporting, flat-pack geometry, derived-weight refresh (wsae_prepare).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -144,6 +145,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     c->dead_list = (int32_t*)(base + o_dl);
     c->row_order = (int32_t*)(base + o_ro);
     c->ws_bytes = cv.total;
+    if (const char* e = getenv("WSAE_DENSE_TOPK")) c->force_dense_topk = atoi(e);  // experiments
     *out = c;
     return WSAE_OK;
 }

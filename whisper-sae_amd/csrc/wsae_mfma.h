@@ -90,32 +90,57 @@ struct Mfma<float> {
 // Dense operand slab: rows [row0, row0+128) x K elements [k0, k0+KT) of a row-major matrix with
 // leading dimension ld (elements).  Rows >= n_rows and K chunks >= k_total read as zero.
 // 1024 16-byte chunks per slab, 4 per thread; 8 consecutive threads cover one 128-byte row.
+// (Four named members, not an array: an array member indexed in an unrolled loop kept the whole
+// struct in scratch memory in the larger kernels.)
 template <typename T>
 struct SlabRegs {
-    uint4 v[4];
+    uint4 v0, v1, v2, v3;
 };
+
+template <typename T>
+__device__ __forceinline__ uint4 slab_chunk(const T* __restrict__ base, int64_t ld, int row0, int n_rows, int k0,
+                                            int k_total, int c) {
+    constexpr int EPC = 16 / (int)sizeof(T);  // elements per chunk
+    const int row = row0 + (c >> 3);
+    const int k = k0 + (c & 7) * EPC;
+    if (row < n_rows && k < k_total) return *(const uint4*)(base + (int64_t)row * ld + k);
+    return make_uint4(0, 0, 0, 0);
+}
 
 template <typename T>
 __device__ __forceinline__ void slab_load(SlabRegs<T>& r, const T* __restrict__ base, int64_t ld, int row0,
                                           int n_rows, int k0, int k_total, int tid) {
-    constexpr int EPC = 16 / (int)sizeof(T);  // elements per chunk
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
-        const int row = row0 + (c >> 3);
-        const int k = k0 + (c & 7) * EPC;
-        if (row < n_rows && k < k_total)
-            r.v[i] = *(const uint4*)(base + (int64_t)row * ld + k);
-        else
-            r.v[i] = make_uint4(0, 0, 0, 0);
-    }
+    r.v0 = slab_chunk<T>(base, ld, row0, n_rows, k0, k_total, tid);
+    r.v1 = slab_chunk<T>(base, ld, row0, n_rows, k0, k_total, tid + 256);
+    r.v2 = slab_chunk<T>(base, ld, row0, n_rows, k0, k_total, tid + 512);
+    r.v3 = slab_chunk<T>(base, ld, row0, n_rows, k0, k_total, tid + 768);
+}
+
+// Same, for callers that guarantee the whole slab is in bounds (rows clamped by the caller): no
+// predicates, so the four loads are straight-line code and hipcc can wait for them with a COUNTED
+// vmcnt instead of draining everything (predicated loads end up behind exec branches and force
+// vmcnt(0), which serialises a two-deep prefetch on the L2 latency).
+template <typename T>
+__device__ __forceinline__ uint4 slab_chunk_fast(const T* __restrict__ base, int64_t ld, int row0, int row_max, int k0,
+                                                 int c) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int row = min(row0 + (c >> 3), row_max);
+    return *(const uint4*)(base + (int64_t)row * ld + k0 + (c & 7) * EPC);
+}
+
+template <typename T>
+__device__ __forceinline__ void slab_load_fast(SlabRegs<T>& r, const T* __restrict__ base, int64_t ld, int row0,
+                                               int row_max, int k0, int tid) {
+    r.v0 = slab_chunk_fast<T>(base, ld, row0, row_max, k0, tid);
+    r.v1 = slab_chunk_fast<T>(base, ld, row0, row_max, k0, tid + 256);
+    r.v2 = slab_chunk_fast<T>(base, ld, row0, row_max, k0, tid + 512);
+    r.v3 = slab_chunk_fast<T>(base, ld, row0, row_max, k0, tid + 768);
 }
 
 template <typename T>
 __device__ __forceinline__ void slab_store(const SlabRegs<T>& r, char* lds, int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
-        *(uint4*)(lds + (c >> 3) * LDS_ROW_BYTES + (c & 7) * 16) = r.v[i];
-    }
+    *(uint4*)(lds + ((tid) >> 3) * LDS_ROW_BYTES + (tid & 7) * 16) = r.v0;
+    *(uint4*)(lds + ((tid + 256) >> 3) * LDS_ROW_BYTES + (tid & 7) * 16) = r.v1;
+    *(uint4*)(lds + ((tid + 512) >> 3) * LDS_ROW_BYTES + (tid & 7) * 16) = r.v2;
+    *(uint4*)(lds + ((tid + 768) >> 3) * LDS_ROW_BYTES + (tid & 7) * 16) = r.v3;
 }
