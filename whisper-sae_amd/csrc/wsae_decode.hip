@@ -168,24 +168,31 @@ decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const fl
 // W_dT is the bf16 shadow in BF16 mode (2.36 MB at cfg2: resident in every XCD's 4 MB L2) and the
 // fp32 master in FP32 mode.
 // ------------------------------------------------------------------------------------------------
+// A lane's EPL elements of a D = 32*EPL row are taken CHUNK-INTERLEAVED: load c of lane li covers
+// bytes [CS*(32*c + li), +CS), so every load instruction of a half-wave reads 32*CS contiguous bytes
+// (whole 128-byte lines).  (A lane-contiguous mapping -- 24 bytes per lane as 3 x 8 -- made each
+// instruction span all six lines of the row: 3x the L2 requests, and the kernel was L2-request bound.)
 template <typename TW, int EPL>
 struct RowSeg {
     static constexpr int NB = EPL * (int)sizeof(TW);                       // bytes per lane
     static constexpr int CS = (NB % 16 == 0) ? 16 : (NB % 8 == 0) ? 8 : 4;  // load width
     static constexpr int NW = NB / 4;                                       // dwords per lane
+    static constexpr int EPC = CS / (int)sizeof(TW);                        // elements per chunk
     uint32_t w[NW];
+    // element index (within the row) of this lane's e-th element
+    static __device__ __forceinline__ int elem(int li, int e) { return (32 * (e / EPC) + li) * EPC + (e % EPC); }
     __device__ __forceinline__ void load(const TW* row, int li) {
-        const char* p = (const char*)row + NB * li;
+        const char* p = (const char*)row + CS * li;
 #pragma unroll
-        for (int o = 0; o < NB; o += CS) {
+        for (int c = 0; c < NB / CS; ++c) {
             if (CS == 16) {
-                const uint4 v = *(const uint4*)(p + o);
-                w[o / 4] = v.x; w[o / 4 + 1] = v.y; w[o / 4 + 2] = v.z; w[o / 4 + 3] = v.w;
+                const uint4 v = *(const uint4*)(p + c * 32 * CS);
+                w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
             } else if (CS == 8) {
-                const uint2 v = *(const uint2*)(p + o);
-                w[o / 4] = v.x; w[o / 4 + 1] = v.y;
+                const uint2 v = *(const uint2*)(p + c * 32 * CS);
+                w[2 * c] = v.x; w[2 * c + 1] = v.y;
             } else {
-                w[o / 4] = *(const uint32_t*)(p + o);
+                w[c] = *(const uint32_t*)(p + c * 32 * CS);
             }
         }
     }
@@ -233,54 +240,112 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
     const float scale = 2.0f / ((float)B * (float)D);
     const int64_t step = (last_activated && step_count) ? *step_count : 0;
 
-    float bsum[EPL], dbd[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        bsum[e] = bd[EPL * li + e] + bpre[EPL * li + e];
-        dbd[e] = 0.f;
+    // b_d + b_pre and the per-wave column sums of g live in LDS, not in registers: the gathered rows
+    // (96 packed registers at 384/k=32) need the room
+    float* bsum_s = dbd_s + 4 * D;  // [D]
+    for (int d = threadIdx.x; d < D; d += 256) {
+        bsum_s[d] = bd[d] + bpre[d];
+        dbd_s[d] = 0.f; dbd_s[D + d] = 0.f; dbd_s[2 * D + d] = 0.f; dbd_s[3 * D + d] = 0.f;
     }
+    __syncthreads();
     float loss_acc = 0.f;
     int l0_acc = 0;
 
-    for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+    // software pipeline over the wave's rows: the compact code and the x row of the NEXT row are requested
+    // before the current row's gathers, so a row costs one exposed L2 round trip (the gathers), not three
+    using Seg = RowSeg<TW, EPL>;
+    constexpr int NCH = Seg::NB / Seg::CS;  // chunks per lane; a chunk is Seg::EPC consecutive elements
+    auto load_x = [&](int bb, float (&xr)[EPL]) {
+        const int64_t src = rows ? (int64_t)rows[bb] : (int64_t)bb;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int64_t o = src * D + (32 * c + li) * Seg::EPC;
+            if (XDT == WSAE_DT_BF16 && Seg::EPC == 4) {
+                const bf16x4 t = *(const bf16x4*)((const bf16_t*)x + o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xr[c * 4 + q] = (float)t[q];
+            } else if (XDT == WSAE_DT_F32 && Seg::EPC == 4) {
+                const float4 t = *(const float4*)((const float*)x + o);
+                xr[c * 4] = t.x; xr[c * 4 + 1] = t.y; xr[c * 4 + 2] = t.z; xr[c * 4 + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < Seg::EPC; ++q) xr[c * Seg::EPC + q] = load_act<XDT>(x, o + q);
+            }
+        }
+    };
+    const int b_first = blockIdx.x * 4 + wave, b_step = gridDim.x * 4;
+    float v_n = 0.f, xr[EPL];
+    int f_n = 0;
+    if (b_first < B) {
+        v_n = (lane < K) ? vals[(int64_t)b_first * K + lane] : 0.f;
+        f_n = (lane < K) ? idx[(int64_t)b_first * K + lane] : 0;
+        load_x(b_first, xr);
+    }
+    for (int b = b_first; b < B; b += b_step) {
         const int64_t code = (int64_t)b * K;
-        const float v_l = (lane < K) ? vals[code + lane] : 0.f;
-        const int f_l = (lane < K) ? idx[code + lane] : 0;
+        const float v_l = v_n;
+        const int f_l = f_n;
         const bool on = v_l > 0.f;
         l0_acc += __popcll(__ballot(on));
         if (on && last_activated) last_activated[f_l] = step;  // model.py:178-181
         const float vr_l = on ? v_l : 0.f;
 
-        RowSeg<TW, EPL> seg[KJ];
+        Seg seg[KJ];
         float acc[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-        // ---- decode: this half accumulates features j = 2*jj + half ----
+        // ---- gathers of this row first, then the requests for the next row ----
+        float vj[KJ];
 #pragma unroll
         for (int jj = 0; jj < KJ; ++jj) {
             const int j = 2 * jj + half;
-            const float vj = __shfl(vr_l, j, 64);
+            vj[jj] = __shfl(vr_l, j, 64);
             const int fj = __shfl(f_l, j, 64);  // lanes >= K carry feature 0, value 0
             seg[jj].load(WdT + (int64_t)fj * D, li);
+        }
+        const bool more = b + b_step < B;
+        if (more) {
+            v_n = (lane < K) ? vals[(int64_t)(b + b_step) * K + lane] : 0.f;
+            f_n = (lane < K) ? idx[(int64_t)(b + b_step) * K + lane] : 0;
+        }
+        // ---- decode: this half accumulates features j = 2*jj + half ----
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(vj, seg[jj].get(e), acc[e]);
+        for (int jj = 0; jj < KJ; ++jj) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(vj[jj], seg[jj].get(e), acc[e]);
         }
         // ---- residual, loss, g (both halves end up with the full sum) ----
-        const int64_t src = rows ? (int64_t)rows[b] : (int64_t)b;
         float g[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const float rec = acc[e] + __shfl_xor(acc[e], 32, 64) + bsum[e];
-            const float xv = load_act<XDT>(x, src * D + EPL * li + e);
-            const float r = rec - xv;
-            g[e] = r * scale;
+        for (int c = 0; c < NCH; ++c) {
+            float rec[Seg::EPC];
+#pragma unroll
+            for (int q = 0; q < Seg::EPC; ++q) {
+                const int e = c * Seg::EPC + q;
+                const int d = (32 * c + li) * Seg::EPC + q;
+                rec[q] = acc[e] + __shfl_xor(acc[e], 32, 64) + bsum_s[d];
+                const float r = rec[q] - xr[e];
+                g[e] = r * scale;
+                if (half == 0) {
+                    loss_acc = fmaf(r, r, loss_acc);
+                    dbd_s[wave * D + d] += g[e];  // this wave's private row of the LDS accumulator
+                }
+            }
             if (half == 0) {
-                loss_acc = fmaf(r, r, loss_acc);
-                dbd[e] += g[e];
-                if (recon_out) recon_out[(int64_t)b * D + EPL * li + e] = rec;
-                if (BWD) g_out[(int64_t)b * D + EPL * li + e] = g[e];
+                const int64_t o = (int64_t)b * D + (32 * c + li) * Seg::EPC;
+                if (Seg::EPC == 4) {
+                    if (recon_out) *(float4*)(recon_out + o) = make_float4(rec[0], rec[1], rec[2], rec[3]);
+                    if (BWD) *(float4*)(g_out + o) = make_float4(g[c * 4], g[c * 4 + 1], g[c * 4 + 2], g[c * 4 + 3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < Seg::EPC; ++q) {
+                        if (recon_out) recon_out[o + q] = rec[q];
+                        if (BWD) g_out[o + q] = g[c * Seg::EPC + q];
+                    }
+                }
             }
         }
+        if (more) load_x(b + b_step, xr);  // lands under the dpre pass
         // ---- dpre_j = (v_j > 0) ? g . W_dT[idx_j, :] : 0 ----
         if (BWD) {
             float pd[KJ];
@@ -314,14 +379,7 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
         }
     }
 
-    if (BWD) {
-        __syncthreads();
-        if (half == 0) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) dbd_s[wave * D + EPL * li + e] = dbd[e];
-        }
-        __syncthreads();
-    }
+    __syncthreads();
     decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, part_loss, part_l0, part_dbd, ticket, stats);
 }
 
@@ -383,7 +441,7 @@ static void launch_decode_fast(wsae_ctx* c, const TW* WdT, const float* params, 
                                int64_t* last_activated, const int64_t* step_count, int nblk, wsae_stats* stats, hipStream_t st) {
     const float* bd = params + c->off[3];
     const float* bpre = params + c->off[4];
-    const size_t sh = (8 + 4 * (size_t)c->D) * sizeof(float);
+    const size_t sh = (8 + 5 * (size_t)c->D) * sizeof(float);
 #define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->K, recon, dpre, c->g, last_activated, step_count, \
                  c->part_loss, c->part_l0, c->part_dbd, c->counters, stats
     if (!want_bwd)
