@@ -91,9 +91,12 @@ int wsae_param_offsets(int32_t input_dim, int32_t hidden_dim, int64_t offsets[5]
 /* ctx: dims + mode + all workspace (bf16 weight shadows, TopK scratch, partial-sum slabs). */
 int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out);
 int wsae_ctx_destroy(wsae_ctx* ctx);
-/* Debug/test switch: 1 = wsae_encode_topk always materialises the dense [B,H] pre-activations and
- * runs the standalone TopK kernel, 0 (default) = fused filter path where the shape qualifies. */
-int wsae_ctx_set_dense_topk(wsae_ctx* ctx, int32_t on);
+/* TopK strategy of wsae_encode_topk.  0 (default): dense pre-activation GEMM + standalone TopK kernel.
+ * 1: fused filter path where the shape qualifies (H >= 1024, k <= 64, B >= 512): a sample pass over every
+ * 8th feature gives a per-row threshold, the GEMM epilogue keeps only candidates above it, and rows the
+ * filter cannot settle are recomputed exactly -- the [B,H] matrix never reaches HBM.  Same results either
+ * way; on MI355X at 384->3072/B=16384 the dense path is currently the faster one. */
+int wsae_ctx_set_fused_topk(wsae_ctx* ctx, int32_t on);
 size_t wsae_ctx_workspace_bytes(const wsae_ctx* ctx);
 
 /* Refresh what the kernels derive from the master weights: bf16 shadow of W_e and the folded

@@ -431,6 +431,13 @@ class TestFusedTopK:
     """The filter path (sample threshold -> filtering GEMM -> select -> exact fallback) against
     torch.topk on the kernel's own dense pre-activations, including inputs that defeat the sample."""
 
+    @staticmethod
+    def _fused(m, batch):
+        """Opt this model's bf16 ctx into the fused filter path (the default is dense GEMM + TopK)."""
+        from whisper_sae import _native as N
+        eng = m.bind()
+        N.check(N.lib().wsae_ctx_set_fused_topk(eng.ctx(N.PREC_BF16, batch), 1), "wsae_ctx_set_fused_topk")
+
     def _model(self, device, bias=None):
         from whisper_sae.sae.model import TopKSAE
         torch.manual_seed(3)
@@ -442,6 +449,7 @@ class TestFusedTopK:
 
     def _check(self, m, x):
         pre = m.pre_activation(x)
+        self._fused(m, x.shape[0])
         vals, idx = m.encode_compact(x)
         tv, ti = torch.topk(pre, 32, dim=-1)
         assert torch.equal(vals, tv)
@@ -471,6 +479,7 @@ class TestFusedTopK:
             m.encoder.weight.zero_()  # all pre-activations equal the bias: ties everywhere
             m.encoder.bias.fill_(0.25)
         x = torch.from_numpy(synth.activations(512, 384, seed=7, stream=0)).to(device)
+        self._fused(m, 512)
         vals, idx = m.encode_compact(x)
         assert torch.all(vals == 0.25)
         assert torch.equal(idx.long(), torch.arange(32, device=device).expand(512, 32))  # lowest indices win ties

@@ -99,7 +99,7 @@ struct wsae_ctx {
     int32_t* cand_cnt;    // [maxB][ceil(H/128)]
     int32_t* cand_ovf;    // [maxB] slot-group overflow flags
     int32_t* flag_rows;   // [maxB] rows sent to the exact fallback
-    int force_dense_topk; // tests: take the dense two-kernel path regardless of shape
+    int fused_topk;       // 1: filter path (sample threshold + filtering GEMM) instead of dense GEMM + TopK
     int n_dec_blocks;     // blocks used by the last decode launch (partials to reduce)
     int n_sq_parts;       // global-norm partials left in part_sq by the last wsae_weight_grads
     float* dbd2;          // [64][D] level-1 reduction of part_dbd

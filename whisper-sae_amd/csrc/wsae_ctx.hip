@@ -145,7 +145,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     c->dead_list = (int32_t*)(base + o_dl);
     c->row_order = (int32_t*)(base + o_ro);
     c->ws_bytes = cv.total;
-    if (const char* e = getenv("WSAE_DENSE_TOPK")) c->force_dense_topk = atoi(e);  // experiments
+    if (const char* e = getenv("WSAE_FUSED_TOPK")) c->fused_topk = atoi(e);  // experiments
     *out = c;
     return WSAE_OK;
 }
@@ -221,9 +221,9 @@ extern "C" int wsae_profile_read(wsae_ctx* ctx, int32_t kernel_id, int32_t* n_la
     return WSAE_OK;
 }
 
-extern "C" int wsae_ctx_set_dense_topk(wsae_ctx* ctx, int32_t on) {
-    WSAE_REQUIRE(ctx, "wsae_ctx_set_dense_topk: null ctx");
-    ctx->force_dense_topk = on ? 1 : 0;
+extern "C" int wsae_ctx_set_fused_topk(wsae_ctx* ctx, int32_t on) {
+    WSAE_REQUIRE(ctx, "wsae_ctx_set_fused_topk: null ctx");
+    ctx->fused_topk = on ? 1 : 0;
     return WSAE_OK;
 }
 

@@ -217,6 +217,113 @@ encode_gemm_kernel(const T* __restrict__ xb, const T* __restrict__ W, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// encode_gemm256_kernel: 256 x 256 output tile, 8 waves (4 x 2, each 128 x 64), LDS double buffer,
+// one barrier per K slab, next slab's operands in flight during the MFMAs.  DENSE only: the
+// pre-activation matrix for the standalone TopK kernel.  Requires D % KT == 0.
+// ------------------------------------------------------------------------------------------------
+#define T256_LDS (256 * LDS_ROW_BYTES)
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(512)
+encode_gemm256_kernel(const T* __restrict__ xb, const T* __restrict__ W, const float* __restrict__ bias,
+                      float* __restrict__ pre, int ldp, int B, int H, int D, const float* __restrict__ thr,
+                      int thr_stride, uint64_t* __restrict__ cand, int32_t* __restrict__ cand_cnt,
+                      int32_t* __restrict__ ovf, int cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* cnt_s = (int*)(smem + 4 * T256_LDS);   // [256] candidates per row   (FILTER)
+    float* thr_s = (float*)(cnt_s + 256);        // [256] row thresholds
+    constexpr int KT = Mfma<T>::KT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves: 128-row halves x 64-column quarters
+    const int m0 = blockIdx.y * 256, n0 = blockIdx.x * 256;
+    const int t2 = tid & 255, half = tid >> 8;  // each 256-thread half stages 128 rows of A and of W
+    if (MODE == GEMM_FILTER && tid < 256) {
+        cnt_s[tid] = 0;
+        thr_s[tid] = (m0 + tid < B) ? thr[(int64_t)(m0 + tid) * thr_stride] : INFINITY;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    SlabRegs<T> ra, rb;
+    slab_load_fast<T>(ra, xb, D, m0 + 128 * half, B - 1, 0, t2);
+    slab_load_fast<T>(rb, W, D, n0 + 128 * half, H - 1, 0, t2);
+    const int nk = D / KT;
+    for (int kt = 0; kt < nk; ++kt) {
+        char* As = smem + (kt & 1) * 2 * T256_LDS;
+        char* Bs = As + T256_LDS;
+        slab_store<T>(ra, As + 128 * half * LDS_ROW_BYTES, t2);
+        slab_store<T>(rb, Bs + 128 * half * LDS_ROW_BYTES, t2);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            slab_load_fast<T>(ra, xb, D, m0 + 128 * half, B - 1, (kt + 1) * KT, t2);
+            slab_load_fast<T>(rb, W, D, n0 + 128 * half, H - 1, (kt + 1) * KT, t2);
+        }
+        Mfma256<T>::slab(As, Bs, wm * 128, wn * 64, lane, acc);
+    }
+    const int col = lane & 31, rq = lane >> 5;
+    if (MODE == GEMM_FILTER) {
+        // keep only elements >= the row threshold: 64-bit keys into the (row, column-tile) list
+        // (write-through stores: the candidate stream must not evict W_e from L2)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            float tv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t4 = *(const float4*)(thr_s + wm * 128 + mi * 32 + 8 * q + 4 * rq);
+                tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int h = n0 + wn * 64 + ni * 32 + col;
+                const bool hin = h < H;
+                const float bv = hin ? bias[h] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[mi][ni][r] + bv;
+                    const bool pass = hin && v >= tv[r];
+                    if (__ballot(pass)) {
+                        if (pass) {
+                            const int rl = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                            const int slot = atomicAdd(&cnt_s[rl], 1);
+                            if (slot < cap)
+                                __hip_atomic_store(cand + ((int64_t)(m0 + rl) * gridDim.x + blockIdx.x) * cap + slot,
+                                                   ((uint64_t)f32_ord(v) << 32) | (uint32_t)(~(uint32_t)h),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 256 && m0 + tid < B) {
+            const int c = cnt_s[tid];
+            cand_cnt[(int64_t)(m0 + tid) * gridDim.x + blockIdx.x] = min(c, cap);
+            if (c > cap) ovf[m0 + tid] = 1;
+        }
+        return;
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int h = n0 + wn * 64 + ni * 32 + col;
+        if (h >= H) continue;
+        const float bv = bias[h];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = m0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                if (b < B) pre[(int64_t)b * ldp + h] = acc[mi][ni][r] + bv;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // encode_rows_kernel: the same contraction, organised around the rows instead of around output tiles.
 // A workgroup owns 128 batch rows for a whole range of feature tiles: its x tile (all of K, <= 6 slabs
 // = 108 KB of LDS) is staged ONCE, and only W_e streams -- half the L2 traffic of the tile kernel and
@@ -629,8 +736,15 @@ static int gemm_dense(wsae_ctx* c, const float* params, int B, int nfeat, int ws
     const float* bias = sizeof(T) == 2 ? c->c_fold : params + c->off[2];
     dim3 gg(ceil_div(nfeat, TILE_N), ceil_div(B, TILE_M));
     WSAE_PROF_BEGIN(c, WSAE_K_ENCODE_GEMM, st);
-    encode_gemm_kernel<T, GEMM_DENSE><<<gg, 256, 2 * TILE_LDS_BYTES, st>>>(
-        (const T*)c->xb, W, bias, pre, ldp, B, nfeat, c->D, wstride, arows, n_dev, nullptr, 0, nullptr, nullptr, nullptr);
+    if (wstride == 1 && !arows && !n_dev && B >= 2048 && nfeat % 256 == 0 && c->D % Mfma<T>::KT == 0) {
+        dim3 g2(nfeat / 256, ceil_div(B, 256));
+        encode_gemm256_kernel<T, GEMM_DENSE><<<g2, 512, 4 * T256_LDS, st>>>(
+            (const T*)c->xb, W, bias, pre, ldp, B, nfeat, c->D, nullptr, 0, nullptr, nullptr, nullptr, 0);
+    } else {
+        encode_gemm_kernel<T, GEMM_DENSE><<<gg, 256, 2 * TILE_LDS_BYTES, st>>>(
+            (const T*)c->xb, W, bias, pre, ldp, B, nfeat, c->D, wstride, arows, n_dev, nullptr, 0, nullptr, nullptr,
+            nullptr);
+    }
     WSAE_PROF_END(c, WSAE_K_ENCODE_GEMM, st);
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;
@@ -667,7 +781,14 @@ static int encode_topk_fused(wsae_ctx* c, const float* params, int B, float* val
     const int nk = ceil_div(D, Mfma<T>::KT);
     int ngroup = ntile, cap = CAND_SLOTS;  // candidate lists: [row][ngroup][cap]
     WSAE_PROF_BEGIN(c, WSAE_K_ENCODE_FILTER, st);
-    if (nk <= ROWS_MAX_KSLABS && nk % 2 == 0 && D % Mfma<T>::KT == 0) {
+    if (H % 256 == 0 && D % Mfma<T>::KT == 0 && B >= 2048) {
+        ngroup = H / 256;
+        cap = 2 * CAND_SLOTS;
+        dim3 g2(ngroup, ceil_div(B, 256));
+        encode_gemm256_kernel<T, GEMM_FILTER><<<g2, 512, 4 * T256_LDS + 2048, st>>>(
+            (const T*)c->xb, W, bias, nullptr, 0, B, H, D, c->thr_vals + (KS - 1), KS, c->cand, c->cand_cnt, c->cand_ovf,
+            cap);
+    } else if (getenv("WSAE_ROWS_KERNEL") && nk <= ROWS_MAX_KSLABS && nk % 2 == 0 && D % Mfma<T>::KT == 0) {
         // row-owner kernel: enough feature-range splits to put a workgroup on every CU
         const int nrb = ceil_div(B, TILE_M);
         int nsp = max(1, min(ntile, ceil_div(256, nrb)));
@@ -733,7 +854,7 @@ extern "C" int wsae_encode_topk(wsae_ctx* ctx, const float* params, const void* 
     hipStream_t st = (hipStream_t)stream;
     int32_t* fb = stats ? &stats->topk_fallback_rows : ctx->counters;
     // fused TopK pays once the [B,H] round trip dominates; small shapes keep the dense two-kernel path
-    const bool fused = ctx->H >= 1024 && ctx->H % 128 == 0 && ctx->K <= 64 && B >= 512 && !ctx->force_dense_topk;
+    const bool fused = ctx->H >= 1024 && ctx->H % 128 == 0 && ctx->K <= 64 && B >= 512 && ctx->fused_topk;
     if (fused) {
         rc = ctx->prec == WSAE_PREC_BF16 ? stage_batch<bf16_t>(ctx, params, x, x_dtype, rows, B, st)
                                          : stage_batch<float>(ctx, params, x, x_dtype, rows, B, st);

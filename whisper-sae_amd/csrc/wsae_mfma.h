@@ -87,6 +87,59 @@ struct Mfma<float> {
     }
 };
 
+// 8-wave / 256 x 256 workgroup tiles: a wave owns 128 rows x 64 columns = 4 x 2 MFMA tiles (128
+// accumulator VGPRs); per 16-deep K step it reads 4 A fragments + 2 B fragments for 8 MFMAs.
+// (Per flop this moves half the operand bytes of the 128 x 128 tile: at K = 384 the 128 x 128 tile needs
+// 64 B/clk/CU of L1 bandwidth at the MFMA peak, i.e. all of it.)
+template <typename T>
+struct Mfma256;
+
+template <>
+struct Mfma256<bf16_t> {
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
+                                                f32x16 (&acc)[4][2]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *(const bf16x8*)(As + (a_row0 + i * 32 + r) * LDS_ROW_BYTES + kk * 32 + h * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                b[i] = *(const bf16x8*)(Bs + (b_row0 + i * 32 + r) * LDS_ROW_BYTES + kk * 32 + h * 16);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+
+template <>
+struct Mfma256<float> {
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
+                                                f32x16 (&acc)[4][2]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *(const float*)(As + (a_row0 + i * 32 + r) * LDS_ROW_BYTES + (kk * 2 + h) * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                b[i] = *(const float*)(Bs + (b_row0 + i * 32 + r) * LDS_ROW_BYTES + (kk * 2 + h) * 4);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+
 // Dense operand slab: rows [row0, row0+128) x K elements [k0, k0+KT) of a row-major matrix with
 // leading dimension ld (elements).  Rows >= n_rows and K chunks >= k_total read as zero.
 // 1024 16-byte chunks per slab, 4 per thread; 8 consecutive threads cover one 128-byte row.
