@@ -308,18 +308,34 @@ encode_gemm256_kernel(const T* __restrict__ xb, const T* __restrict__ W, const f
         }
         return;
     }
+    // ---- dense epilogue: 16-byte row stores.  Each wave transposes its accumulators through a private
+    // 32 x 64 LDS patch (the operand buffers are free now), so a store instruction writes four 256-byte
+    // row pieces instead of two 128-byte ones and there are 32 of them per lane instead of 128: the tail
+    // of this kernel is store-issue bound, not bandwidth bound.
+    __syncthreads();  // every wave is done reading the operand buffers
+    constexpr int PS = 68;  // patch row stride in floats (64 + 4: the two half-waves land on disjoint banks)
+    float* patch = (float*)smem + wave * 32 * PS;
+    const int pr = lane >> 4, pc = (lane & 15) * 4;  // read-back: 16 lanes per row, float4 each
+    const int hcol = n0 + wn * 64 + pc;
+    float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hcol < H) bv4 = *(const float4*)(bias + hcol);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int h = n0 + wn * 64 + ni * 32 + col;
-        if (h >= H) continue;
-        const float bv = bias[h];
+    for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = m0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-                if (b < B) pre[(int64_t)b * ldp + h] = acc[mi][ni][r] + bv;
-            }
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * rq) * PS + ni * 32 + col] = acc[mi][ni][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rl = pr + 4 * i;
+            const int b = m0 + wm * 128 + mi * 32 + rl;
+            float4 v = *(const float4*)(patch + rl * PS + pc);
+            v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+            if (b < B && hcol < H) *(float4*)(pre + (int64_t)b * ldp + hcol) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -628,6 +644,99 @@ __global__ void __launch_bounds__(256) topk_kernel(const float* __restrict__ pre
 }
 
 // ------------------------------------------------------------------------------------------------
+// topk_rows_kernel: the common case of topk_kernel (K <= 64, H <= 256*VPL <= 4096) with the row held
+// in registers (VPL float4 per lane), read from HBM exactly once:
+//   lane maxima -> K-th largest lane maximum T (bitonic sort over the 64 lanes) -> every lane files
+//   its own elements >= T into a private LDS strip (no ballots, no atomics) -> wave prefix sum of the
+//   strip lengths -> dense list -> bitonic sort -> the K best.  A lane with more than TOPK_STRIP
+//   survivors, or more than TOPK_CAP in total (ties, adversarial layouts), hands the row to the
+//   generic kernel's exact bisection path (same launch, same outputs).
+// ------------------------------------------------------------------------------------------------
+#define TOPK_STRIP 8
+
+__device__ void topk_row_generic(const float* row, int H, int K, uint64_t* list, int lane, float* vrow, int32_t* irow,
+                                 int32_t* fallback_rows);
+
+template <int VPL>
+__global__ void __launch_bounds__(256)
+topk_rows_kernel(const float* __restrict__ pre, int B, int H, int K, float* __restrict__ vals,
+                 int32_t* __restrict__ idx, int64_t* __restrict__ step_count, int32_t* __restrict__ fallback_rows) {
+    __shared__ uint64_t lists[4][TOPK_CAP];
+    __shared__ uint64_t strips[4][64 * TOPK_STRIP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && step_count) *step_count += 1;  // model.py:175
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const float* row = pre + (int64_t)b * H;
+    uint64_t* list = lists[wave];
+    uint64_t* strip = strips[wave] + lane * TOPK_STRIP;
+
+    float4 v[VPL];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int e = lane * 4 + 256 * i;
+        v[i] = e < H ? *(const float4*)(row + e) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        m = fmaxf(fmaxf(m, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+    }
+    uint64_t mk[1] = {(uint64_t)f32_ord(m) << 32};
+    wave_sort_desc<1>(mk, lane);
+    const uint32_t thi = __shfl((uint32_t)(mk[0] >> 32), K - 1, 64);  // ord(T): 64 distinct elements are >= T
+
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float vv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t o = f32_ord(vv[c]);
+            if (o >= thi && lane * 4 + 256 * i + c < H) {
+                if (cnt < TOPK_STRIP) strip[cnt] = ((uint64_t)o << 32) | (uint32_t)(~(uint32_t)(lane * 4 + 256 * i + c));
+                ++cnt;
+            }
+        }
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    const int total = __shfl(incl, 63, 64);
+    float* vrow = vals + (int64_t)b * K;
+    int32_t* irow = idx + (int64_t)b * K;
+    if (__any(cnt > TOPK_STRIP) || total > TOPK_CAP || total < K) {
+        topk_row_generic(row, H, K, list, lane, vrow, irow, fallback_rows);
+        return;
+    }
+    const int off = incl - cnt;
+    for (int s_ = 0; s_ < cnt; ++s_) list[off + s_] = strip[s_];
+    __builtin_amdgcn_wave_barrier();
+    if (total <= 64)
+        topk_emit<1>(list, total, K, lane, vrow, irow);
+    else if (total <= 128)
+        topk_emit<2>(list, total, K, lane, vrow, irow);
+    else
+        topk_emit<4>(list, total, K, lane, vrow, irow);
+}
+
+// exact path shared with topk_kernel: bisection on the 64-bit key for the K-th largest key
+__device__ void topk_row_generic(const float* row, int H, int K, uint64_t* list, int lane, float* vrow, int32_t* irow,
+                                 int32_t* fallback_rows) {
+    if (lane == 0) atomicAdd(fallback_rows, 1);
+    uint64_t prefix = 0;
+    for (int bit = 63; bit >= 0; --bit) {
+        const uint64_t cand = prefix | (1ull << bit);
+        if (topk_count_ge(row, H, cand, lane) >= K) prefix = cand;
+    }
+    const int count = topk_compact(row, H, prefix, list, lane);  // == K exactly (keys are distinct)
+    if (count <= 64)
+        topk_emit<1>(list, count, K, lane, vrow, irow);
+    else
+        topk_emit<2>(list, count, K, lane, vrow, irow);
+}
+
+// ------------------------------------------------------------------------------------------------
 // select_kernel: final TopK of the fused path.  One wave per row gathers the row's candidates from its
 // per-tile slot groups (lanes over tiles, ballot-free prefix via wave scan), and if they are a
 // complete answer (>= K candidates, no slot group overflowed, <= TOPK_CAP in total) sorts them and
@@ -866,7 +975,16 @@ extern "C" int wsae_encode_topk(wsae_ctx* ctx, const float* params, const void* 
                                      : stage_and_gemm<float>(ctx, params, x, x_dtype, rows, B, ctx->pre, st);
     if (rc) return rc;
     WSAE_PROF_BEGIN(ctx, WSAE_K_TOPK, st);
-    topk_kernel<<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb, nullptr, nullptr);
+    const int vpl = ceil_div(ctx->H, 256);
+    if (ctx->K <= 64 && vpl <= 4)
+        topk_rows_kernel<4><<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb);
+    else if (ctx->K <= 64 && vpl <= 12)
+        topk_rows_kernel<12><<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb);
+    else if (ctx->K <= 64 && vpl <= 16)
+        topk_rows_kernel<16><<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb);
+    else
+        topk_kernel<<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb, nullptr,
+                                                    nullptr);
     WSAE_PROF_END(ctx, WSAE_K_TOPK, st);
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;
