@@ -74,7 +74,7 @@ adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restri
 //   SHADOW   : bf16 shadows of W_e[h,:] and W_dT[h,:], folded bias c[h] = b_e[h] - bf16(W_e)[h,:] . b_pre
 //   dead scan: (step_count - last_activated[h]) > threshold counted into the stats record by the last
 //              block to arrive (integer atomics: deterministic)        model.py:183-195
-#define REFRESH_ROWS 8  // feature rows per block (2 per wave): few blocks -> few same-address atomics
+#define REFRESH_ROWS 4  // feature rows per block: one per wave
 template <bool NORMALIZE, bool SHADOW>
 __global__ void __launch_bounds__(256)
 refresh_kernel(const float* __restrict__ We, float* __restrict__ WdT, const float* __restrict__ be,
@@ -183,6 +183,165 @@ static int launch_refresh(wsae_ctx* ctx, float* params, bool normalize, const in
     return WSAE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// update_rows_kernel: the whole optimizer tail in ONE launch, organised by feature row h.
+//   clip coefficient from the norm partials -> AdamW on W_e[h,:], W_dT[h,:], b_e[h] -> unit-norm
+//   W_dT[h,:] -> bf16 shadows + folded bias -> dead-feature count.  b_d and b_pre (2D values) are
+//   updated redundantly by every block in registers (the folded bias needs the NEW b_pre) and written
+//   back by block 0 only.  One pass: 28 B/param of traffic, no separate AdamW / renorm / refresh passes.
+// ------------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float max_norm, grad_scale, part_scale, decay, beta1, beta2, eps, step_size, bc2_sqrt;
+};
+
+__device__ __forceinline__ float adam1(float p, float g, float& m, float& v, const AdamArgs& a, float gs) {
+    const float gc = g * gs;
+    m = m + (gc - m) * (1.f - a.beta1);
+    v = a.beta2 * v + (1.f - a.beta2) * gc * gc;
+    return p * a.decay - a.step_size * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
+}
+
+template <bool NORMALIZE, bool SHADOW>
+__global__ void __launch_bounds__(256)
+update_rows_kernel(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M, float* __restrict__ V,
+                   int64_t oWe, int64_t oWd, int64_t oBe, int64_t oBd, int64_t oBp, int H, int D,
+                   const float* __restrict__ part_sq, int nparts, AdamArgs a, bf16_t* __restrict__ We16,
+                   bf16_t* __restrict__ WdT16, float* __restrict__ cfold, const int64_t* __restrict__ last,
+                   const int64_t* __restrict__ step_count, int64_t thr, int32_t* __restrict__ counters,
+                   wsae_stats* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* bp_s = (float*)smem;  // [D] updated b_pre
+    __shared__ float red[8];
+    __shared__ float gs_s;
+    __shared__ int dead_s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) sq += part_sq[i];
+    const float tot = block_sum(sq, red);
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(tot) * a.part_scale;
+        float coef = 1.f;
+        if (a.max_norm > 0.f) coef = fminf(1.f, a.max_norm / (nrm + 1e-6f));
+        gs_s = coef * a.grad_scale;
+        if (blockIdx.x == 0 && stats) {
+            stats->grad_norm = nrm;
+            stats->clip_coef = coef;
+        }
+    }
+    __syncthreads();
+    const float gs = gs_s;
+    // the NEW b_pre, computed by every block from the old state with identical arithmetic (the folded
+    // bias needs it); the state itself is written once, by the last block to arrive (see the end)
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float m = M[oBp + d], v = V[oBp + d];
+        bp_s[d] = adam1(P[oBp + d], G[oBp + d], m, v, a, gs);
+    }
+    __syncthreads();
+    int dead = 0;
+    constexpr int RPW = REFRESH_ROWS / 4;
+    const int hbase = blockIdx.x * REFRESH_ROWS + wave * RPW;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int h = hbase + r;
+        if (h >= H) break;
+        // ---- W_e row: AdamW, shadow, folded-bias dot ----
+        float dot = 0.f;
+        for (int d = lane * 4; d < D; d += 256) {
+            const int64_t o = oWe + (int64_t)h * D + d;
+            float4 p = *(const float4*)(P + o), m = *(const float4*)(M + o), v = *(const float4*)(V + o);
+            const float4 g = *(const float4*)(G + o);
+            p.x = adam1(p.x, g.x, m.x, v.x, a, gs); p.y = adam1(p.y, g.y, m.y, v.y, a, gs);
+            p.z = adam1(p.z, g.z, m.z, v.z, a, gs); p.w = adam1(p.w, g.w, m.w, v.w, a, gs);
+            *(float4*)(P + o) = p; *(float4*)(M + o) = m; *(float4*)(V + o) = v;
+            if (SHADOW) {
+                bf16x4 e;
+                e[0] = (bf16_t)p.x; e[1] = (bf16_t)p.y; e[2] = (bf16_t)p.z; e[3] = (bf16_t)p.w;
+                *(bf16x4*)(We16 + (int64_t)h * D + d) = e;
+                const float4 bp = *(const float4*)(bp_s + d);
+                dot = fmaf((float)e[0], bp.x, dot); dot = fmaf((float)e[1], bp.y, dot);
+                dot = fmaf((float)e[2], bp.z, dot); dot = fmaf((float)e[3], bp.w, dot);
+            }
+        }
+        // ---- b_e[h] ----
+        float nbe = 0.f;
+        if (lane == 0) {
+            float m = M[oBe + h], v = V[oBe + h];
+            nbe = adam1(P[oBe + h], G[oBe + h], m, v, a, gs);
+            P[oBe + h] = nbe; M[oBe + h] = m; V[oBe + h] = v;
+        }
+        if (SHADOW) {
+            dot = wave_sum(dot);
+            if (lane == 0) cfold[h] = nbe - dot;
+        }
+        // ---- W_dT row: AdamW, unit norm, shadow (row kept in registers between the two passes) ----
+        float4 wd[8];
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = lane * 4 + 256 * i;
+            if (d < D) {
+                const int64_t o = oWd + (int64_t)h * D + d;
+                float4 p = *(const float4*)(P + o), m = *(const float4*)(M + o), v = *(const float4*)(V + o);
+                const float4 g = *(const float4*)(G + o);
+                p.x = adam1(p.x, g.x, m.x, v.x, a, gs); p.y = adam1(p.y, g.y, m.y, v.y, a, gs);
+                p.z = adam1(p.z, g.z, m.z, v.z, a, gs); p.w = adam1(p.w, g.w, m.w, v.w, a, gs);
+                *(float4*)(M + o) = m; *(float4*)(V + o) = v;
+                wd[i] = p;
+                s2 += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
+            }
+        }
+        float inv = 1.f;
+        if (NORMALIZE) {
+            s2 = wave_sum(s2);
+            inv = 1.f / fmaxf(sqrtf(s2), 1e-12f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = lane * 4 + 256 * i;
+            if (d < D) {
+                float4 p = wd[i];
+                p.x *= inv; p.y *= inv; p.z *= inv; p.w *= inv;
+                *(float4*)(P + oWd + (int64_t)h * D + d) = p;
+                if (SHADOW) {
+                    bf16x4 o16;
+                    o16[0] = (bf16_t)p.x; o16[1] = (bf16_t)p.y; o16[2] = (bf16_t)p.z; o16[3] = (bf16_t)p.w;
+                    *(bf16x4*)(WdT16 + (int64_t)h * D + d) = o16;
+                }
+            }
+        }
+        if (last) dead += ((*step_count - last[h]) > thr) ? 1 : 0;
+    }
+    // arrival ticket (low word also sums the dead-feature count); every block's reads of the old
+    // b_pre / b_d state precede its ticket, so the last arriver may overwrite that state
+    if (lane == 0) dead_s[wave] = dead;
+    __syncthreads();
+    __shared__ int last_blk;
+    if (threadIdx.x == 0) {
+        unsigned long long* c64 = (unsigned long long*)(counters + 2);
+        const unsigned long long add = (1ull << 32) | (unsigned long long)(dead_s[0] + dead_s[1] + dead_s[2] + dead_s[3]);
+        const unsigned long long old = __hip_atomic_fetch_add(c64, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_blk = (old >> 32) == gridDim.x - 1;
+        if (last_blk) {
+            __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last && stats) {
+                const int t = (int)((old + add) & 0xFFFFFFFFull);
+                stats->dead_count = t;
+                stats->dead_ratio = (float)t / (float)H;
+            }
+        }
+    }
+    __syncthreads();
+    if (!last_blk) return;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float m = M[oBp + d], v = V[oBp + d];
+        const float np = adam1(P[oBp + d], G[oBp + d], m, v, a, gs);
+        P[oBp + d] = np; M[oBp + d] = m; V[oBp + d] = v;
+        float md = M[oBd + d], vd = V[oBd + d];
+        const float nd = adam1(P[oBd + d], G[oBd + d], md, vd, a, gs);
+        P[oBd + d] = nd; M[oBd + d] = md; V[oBd + d] = vd;
+    }
+}
+
 extern "C" int wsae_normalize_decoder(wsae_ctx* ctx, float* params, void* stream) {
     WSAE_REQUIRE(ctx && params, "wsae_normalize_decoder: null argument");
     return launch_refresh(ctx, params, true, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
@@ -218,13 +377,24 @@ extern "C" int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads,
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    const int nb2 = (int)min((int64_t)2048, ceil_div64(n4, 256));
+    AdamArgs a;
+    a.max_norm = max_norm; a.grad_scale = grad_scale; a.part_scale = part_scale; a.decay = 1.f - lr * weight_decay;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.step_size = step_size; a.bc2_sqrt = bc2_sqrt;
+    const int nb = ceil_div(ctx->H, REFRESH_ROWS);
+    const size_t sh = (size_t)ctx->D * sizeof(float);
+    const bool shadow = ctx->prec == WSAE_PREC_BF16;
+#define UP_ARGS params, grads, exp_avg, exp_avg_sq, ctx->off[0], ctx->off[1], ctx->off[2], ctx->off[3], ctx->off[4], ctx->H, \
+                ctx->D, ctx->part_sq, nparts, a, ctx->We_bf16, ctx->WdT_bf16, ctx->c_fold, last_activated, step_count, \
+                dead_threshold, ctx->counters, stats
     WSAE_PROF_BEGIN(ctx, WSAE_K_ADAMW, st);
-    adamw_kernel<<<nb2, 256, 0, st>>>(params, grads, exp_avg, exp_avg_sq, n4, ctx->part_sq, nparts, part_scale, max_norm,
-                                      grad_scale, lr * weight_decay, beta1, beta2, eps, step_size, bc2_sqrt, stats);
+    if (normalize_decoder && shadow) update_rows_kernel<true, true><<<nb, 256, sh, st>>>(UP_ARGS);
+    else if (normalize_decoder) update_rows_kernel<true, false><<<nb, 256, sh, st>>>(UP_ARGS);
+    else if (shadow) update_rows_kernel<false, true><<<nb, 256, sh, st>>>(UP_ARGS);
+    else update_rows_kernel<false, false><<<nb, 256, sh, st>>>(UP_ARGS);
     WSAE_PROF_END(ctx, WSAE_K_ADAMW, st);
+#undef UP_ARGS
     WSAE_LAUNCH_CHECK();
-    return launch_refresh(ctx, params, normalize_decoder != 0, last_activated, step_count, dead_threshold, stats, st);
+    return WSAE_OK;
 }
 
 // ---- dead features -------------------------------------------------------------------------------

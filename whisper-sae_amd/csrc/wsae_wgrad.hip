@@ -133,21 +133,20 @@ wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid
     int n_lo = 0, n_n = 0;   // ... and of the chunk after it (offsets run one chunk ahead of the entries)
     uint32_t e_pos = 0;      // first NTHR entries: one per thread
     T e_val = (T)0.f;
+    // All loads below are unpredicated (indices clamped instead): predicated loads sit behind exec
+    // branches, and hipcc then drains every outstanding load (vmcnt(0)) at the next use.
     auto offsets = [&](int ck) {
-        if (ck < c_end) {
-            const int32_t* o = ent_off + (int64_t)ck * (ntm + 1) + tm;
-            n_lo = o[0];
-            n_n = o[1] - n_lo;
-        }
+        const int32_t* o = ent_off + (int64_t)min(ck, nchunks - 1) * (ntm + 1) + tm;
+        n_lo = o[0];
+        n_n = o[1] - n_lo;
     };
     auto fetch = [&](int ck) {  // entry range of ck must already sit in (n_lo, n_n)
-        slab_load<T>(rb, Bt, ldT, d0, D, ck * KT, ldT, gtid);
+        slab_load_fast<T>(rb, Bt, ldT, d0, D - 1, ck * KT, gtid);  // rows past D repeat row D-1: never stored
         e_lo = n_lo;
         e_n = n_n;
-        if (tid < e_n) {
-            e_pos = ent_pos[e_lo + tid];
-            e_val = sv[e_lo + tid];
-        }
+        const int ei = e_lo + min(tid, max(e_n - 1, 0));  // lanes past the bucket re-read its last entry
+        e_pos = ent_pos[ei];
+        e_val = sv[ei];
         offsets(ck + 1);
     };
     if (c_begin < c_end) {
