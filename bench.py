@@ -44,6 +44,9 @@ def cpu_baseline(batch: int, budget_s: float = 20.0) -> dict:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    # a 1-GPU box gives this process a 16-core share of the host; oversubscribing the 256 visible
+    # hardware threads made torch ~10x slower.  WSAE_CPU_THREADS overrides.
+    cores = int(os.environ.get("WSAE_CPU_THREADS", min(cores, 16)))
     torch.set_num_threads(cores)
     w = synth.sae_weights(D_MODEL, HIDDEN, seed=42, bf16=False)
     step = TorchCPUStep(w, TOPK, lr=1e-4, weight_decay=0.0, max_norm=1.0)

@@ -194,8 +194,10 @@ def backward(st: SAEState, x: np.ndarray, fwd: dict, mode: str = "fp32") -> dict
     g = (2.0 * (fwd["reconstructed"].astype(F64) - x.astype(F64)) / (B * D)).astype(F32)
     g64 = g.astype(F64)
     db_d = g64.sum(axis=0)
-    w_d = bf16_round(st.W_d) if mode == "amp" else st.W_d  # the decoder weights the forward used
-    dh = g64 @ w_d.astype(F64)  # [B, H]
+    if mode == "amp":  # bf16 decoder shadow against bf16(g): what the dot2 instruction is fed
+        dh = bf16_round(g).astype(F64) @ bf16_round(st.W_d).astype(F64)
+    else:
+        dh = g64 @ st.W_d.astype(F64)  # [B, H]
     dpre = np.where(hidden > 0, dh, 0.0)
     if mode == "fp32":
         xc = (x - st.b_pre).astype(F64)

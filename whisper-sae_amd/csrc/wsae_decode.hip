@@ -309,10 +309,32 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
             f_n = (lane < K) ? idx[(int64_t)(b + b_step) * K + lane] : 0;
         }
         // ---- decode: this half accumulates features j = 2*jj + half ----
+        if constexpr (sizeof(TW) == 2) {
+            // bf16 rows: two elements per packed word -> one v_pk_fma_f32 per word
+            f32x2 acc2[EPL / 2];
 #pragma unroll
-        for (int jj = 0; jj < KJ; ++jj) {
+            for (int q = 0; q < EPL / 2; ++q) acc2[q] = f32x2{0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(vj[jj], seg[jj].get(e), acc[e]);
+            for (int jj = 0; jj < KJ; ++jj) {
+                const f32x2 v2 = {vj[jj], vj[jj]};
+#pragma unroll
+                for (int q = 0; q < EPL / 2; ++q) {
+                    const uint32_t u = seg[jj].w[q];
+                    const f32x2 w2 = {__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u)};
+                    acc2[q] = __builtin_elementwise_fma(w2, v2, acc2[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < EPL / 2; ++q) {
+                acc[2 * q] = acc2[q].x;
+                acc[2 * q + 1] = acc2[q].y;
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < KJ; ++jj) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc[e] = fmaf(vj[jj], seg[jj].get(e), acc[e]);
+            }
         }
         // ---- residual, loss, g (both halves end up with the full sum) ----
         float g[EPL];
@@ -356,8 +378,20 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
 #pragma unroll
                 for (int q = 0; q < RowSeg<TW, EPL>::NW; ++q) asm volatile("" : "+v"(seg[jj].w[q]));
                 float dot = 0.f;
+                if constexpr (sizeof(TW) == 2) {
+                    // bf16 rows against bf16(g): v_dot2c_f32_bf16, exact products, fp32 accumulate
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) dot = fmaf(g[e], seg[jj].get(e), dot);
+                    for (int q = 0; q < EPL / 2; ++q) {
+                        bf16x2 gq;
+                        gq[0] = (bf16_t)g[2 * q];
+                        gq[1] = (bf16_t)g[2 * q + 1];
+                        const uint32_t u = seg[jj].w[q];
+                        dot = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2*)&u, gq, dot, false);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) dot = fmaf(g[e], seg[jj].get(e), dot);
+                }
                 pd[jj] = dot;
             }
             // transposing butterfly over the 32 lanes of each half: a stage with lane mask m halves

@@ -17,6 +17,8 @@
 // that range's xT/gT columns and compact code (2048 rows at cfg2 = 3.6 MB): each XCD streams its
 // share of the batch from HBM once and the 144 tiles re-read it from L2.  Every split writes a
 // private fp32 slab; a second kernel sums the slabs in fixed order (deterministic, no float atomics).
+#include <stdlib.h>
+
 #include "wsae_common.h"
 #include "wsae_mfma.h"
 
@@ -320,6 +322,30 @@ __global__ void __launch_bounds__(256) bias_finish_kernel(const float* __restric
     if (threadIdx.x == 0) part_sq[sq_base + blockIdx.x] = t;
 }
 
+// Split-K factor.  A workgroup walks ceil(nchunks / nsplit) batch chunks and the grid runs in
+// ceil(tiles * nsplit / resident workgroups) rounds, so the kernel time goes like rounds * chunks per
+// split; every split also costs one slab written and re-read (the small per-split term).  At
+// H = 3072, D = 384, B = 16384 on 256 CUs this picks 5 (240 workgroups, one round of 52 chunks:
+// 121 us measured) over 8 (384 workgroups, two rounds of 32: 135 us) and 4 (139 us).
+static int pick_nsplit(wsae_ctx* ctx, int tiles, int nchunks, int nt) {
+    static int cus = 0;
+    if (!cus) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1)
+            cus = 256;
+    }
+    if (const char* e = getenv("WSAE_NSPLIT")) return max(1, min(WSAE_WGRAD_MAX_SPLIT, atoi(e)));  // experiments
+    const int resident = cus * (nt == 1 ? 2 : 1);  // LDS: 72 KB per workgroup at NT = 1, 108 / 144 KB above
+    int best = 1;
+    int64_t best_cost = INT64_MAX;
+    for (int ns = 1; ns <= WSAE_WGRAD_MAX_SPLIT; ++ns) {
+        if (ns > 1 && nchunks / ns < 4) break;  // >= 4 chunks per split
+        const int64_t rounds = ceil_div(tiles * ns, resident);
+        const int64_t cost = rounds * ceil_div(nchunks, ns) * 16 + 24 * ns;  // 16ths of a chunk time; a slab ~ 1.5 chunks
+        if (cost < best_cost) { best_cost = cost; best = ns; }
+    }
+    return best;
+}
+
 template <typename T>
 static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const float* vals, const int32_t* idx,
                          const float* dpre, int B, int ldT, int nsplit, int ntm, int ntn, float* out,
@@ -355,7 +381,7 @@ extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void*
     const int ncol = ceil_div(D, TILE_N);
     const int nt = (ncol % 3 == 0) ? 3 : (ncol % 2 == 0) ? 2 : 1;
     const int ntm = ceil_div(H, TILE_M), ntn = ncol / nt;
-    const int nsplit = min(WSAE_WGRAD_MAX_SPLIT, max(1, nchunks / 4));  // >= 4 chunks per split; 8 = one per XCD
+    const int nsplit = pick_nsplit(ctx, ntm * ntn * 2, nchunks, nt);
     const int64_t slab_stride = 2 * (int64_t)H * D;
     WSAE_REQUIRE(ntm <= BUCKET_MAX_TILES, "hidden_dim %d too large for the bucket pass (max %d)", H, BUCKET_MAX_TILES * 128);
     dim3 grid(ntm * ntn * 2 * nsplit);
