@@ -197,3 +197,104 @@ __device__ __forceinline__ void slab_store(const SlabRegs<T>& r, char* lds, int 
     *(uint4*)(lds + ((tid + 512) >> 3) * LDS_ROW_BYTES + (tid & 7) * 16) = r.v2;
     *(uint4*)(lds + ((tid + 768) >> 3) * LDS_ROW_BYTES + (tid & 7) * 16) = r.v3;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Swizzled, unpadded operand image (weight-gradient kernel v2).  Rows are exactly 128 bytes (64 bf16
+// or 32 f32 along K); the 16-byte chunk c of row r lives at slot c ^ ((r >> 1) & 7).  ds_read_b128
+// serves 16-lane groups against 64 banks = two rows per bank line, and every group's rows
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: MI355X_MICROARCH.md, LDS) split into 8 even + 8 odd
+// rows whose (r >> 1) & 7 are all different, so a fragment read (lanes = rows, same chunk) is
+// conflict-free without the 16 pad bytes - which is what lets a global_load_lds_dwordx4 fill the
+// image directly: one wave-instruction writes 1 KB = 8 whole rows, lane i -> row i>>3, slot i&7,
+// and the swizzle is applied to the per-lane SOURCE address instead (cdna guide, rule 21).
+// ------------------------------------------------------------------------------------------------
+#define SWZ_ROW_BYTES 128
+
+__device__ __forceinline__ int swz_off(int row, int chunk) {
+    return row * SWZ_ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// wave tile 96 x 96 = 3 x 3 MFMA tiles (144 accumulator VGPRs): 6 fragment reads per 9 MFMAs
+template <typename T>
+struct Mfma96;
+
+template <>
+struct Mfma96<bf16_t> {
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
+                                                f32x16 (&acc)[3][3]) {
+        const int r = lane & 31, h = lane >> 5;
+        const int sw = (r >> 1) & 7;  // a_row0, b_row0 and the 32-row steps are multiples of 32: they do not change the swizzle
+        const char* ap = As + (a_row0 + r) * SWZ_ROW_BYTES;
+        const char* bp = Bs + (b_row0 + r) * SWZ_ROW_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int co = ((kk * 2 + h) ^ sw) << 4;
+            bf16x8 a[3], b[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                a[i] = *(const bf16x8*)(ap + i * 32 * SWZ_ROW_BYTES + co);
+                b[i] = *(const bf16x8*)(bp + i * 32 * SWZ_ROW_BYTES + co);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 3; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    // row sums of the 16-row tile at row0 (+= over the chunk), every column of rs holds them
+    static __device__ __forceinline__ void rowsum16(const char* As, int row0, int lane, f32x4& rs) {
+        const int r = row0 + (lane & 15), q = lane >> 4;
+        bf16x8 ones;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const bf16x8 a = *(const bf16x8*)(As + swz_off(r, k2 * 4 + q));
+            rs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, rs, 0, 0, 0);
+        }
+    }
+};
+
+// f32: a lane's 16-byte read holds 4 consecutive k; MFMA step j of read cc pairs element j of the
+// h = 0 lanes (k = 8 cc + j) with element j of the h = 1 lanes (k = 8 cc + 4 + j).  A and B use the
+// same k permutation, so the contraction is unchanged.
+template <>
+struct Mfma96<float> {
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
+                                                f32x16 (&acc)[3][3]) {
+        const int r = lane & 31, h = lane >> 5;
+        const int sw = (r >> 1) & 7;
+        const char* ap = As + (a_row0 + r) * SWZ_ROW_BYTES;
+        const char* bp = Bs + (b_row0 + r) * SWZ_ROW_BYTES;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int co = ((cc * 2 + h) ^ sw) << 4;
+            f32x4 a[3], b[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                a[i] = *(const f32x4*)(ap + i * 32 * SWZ_ROW_BYTES + co);
+                b[i] = *(const f32x4*)(bp + i * 32 * SWZ_ROW_BYTES + co);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 3; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    static __device__ __forceinline__ void rowsum16(const char* As, int row0, int lane, f32x4& rs) {
+        const int r = row0 + (lane & 15), q = lane >> 4;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const f32x4 a = *(const f32x4*)(As + swz_off(r, k2 * 4 + q));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rs = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], 1.0f, rs, 0, 0, 0);
+        }
+    }
+};

@@ -23,9 +23,10 @@
 #include "wsae_mfma.h"
 
 // ------------------------------------------------------------------------------------------------
-// bucket_kernel: per KT-row chunk, counting-sort the chunk's KT*K compact entries by 128-feature tile.
+// bucket_kernel: per KT-row chunk, counting-sort the chunk's KT*K compact entries by tw-feature tile
+// (tw = 128 for wgrad_kernel, 192 for wgrad2_kernel).
 //   ent_off[chunk][t] .. ent_off[chunk][t+1] : positions (in the flat sorted arrays) of the entries of
-//   tile t;  ent_pos = (feature & 127) << 16 | row-in-chunk;  ent_hid = relu(value), ent_dpre = dpre.
+//   tile t;  ent_pos = (feature - t * tw) << 16 | row-in-chunk;  ent_hid = relu(value), ent_dpre = dpre.
 // A (tile, chunk) workgroup of the contraction then touches only its own ~KT*K*128/H entries
 // instead of scanning all KT*K of them for a 128/H hit rate.
 // ------------------------------------------------------------------------------------------------
@@ -34,7 +35,7 @@
 template <typename T>
 __global__ void __launch_bounds__(256)
 bucket_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, const float* __restrict__ dpre, int B,
-              int K, int ntiles, uint32_t* __restrict__ ent_pos, T* __restrict__ ent_hid, T* __restrict__ ent_dpre,
+              int K, int ntiles, int tw, uint32_t* __restrict__ ent_pos, T* __restrict__ ent_hid, T* __restrict__ ent_dpre,
               int32_t* __restrict__ ent_off) {
     __shared__ int cnt[BUCKET_MAX_TILES];
     __shared__ int cur[BUCKET_MAX_TILES];
@@ -45,7 +46,7 @@ bucket_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, c
     const int64_t base = (int64_t)b0 * K;
     for (int t = tid; t < ntiles; t += 256) cnt[t] = 0;
     __syncthreads();
-    for (int e = tid; e < nent; e += 256) atomicAdd(&cnt[idx[base + e] >> 7], 1);
+    for (int e = tid; e < nent; e += 256) atomicAdd(&cnt[idx[base + e] / tw], 1);
     __syncthreads();
     if (tid < 64) {  // exclusive scan over tiles by one wave
         int carry = 0;
@@ -69,9 +70,10 @@ bucket_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, c
     __syncthreads();
     for (int e = tid; e < nent; e += 256) {
         const int f = idx[base + e];
-        const int p = atomicAdd(&cur[f >> 7], 1);
+        const int t = f / tw;
+        const int p = atomicAdd(&cur[t], 1);
         const float v = vals[base + e];
-        ent_pos[base + p] = ((uint32_t)(f & 127) << 16) | (uint32_t)(e / K);
+        ent_pos[base + p] = ((uint32_t)(f - t * tw) << 16) | (uint32_t)(e / K);
         ent_hid[base + p] = (T)(v > 0.f ? v : 0.f);
         ent_dpre[base + p] = (T)dpre[base + e];
     }
@@ -198,6 +200,181 @@ wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid
                 const int f = f0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
                 if (f < H) dbe_slab[(int64_t)split * H + f] = rs[mi][r];
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad2_kernel: the same contraction on a 192-feature x 384-column workgroup tile (D > 256).
+//   * 8 waves as 2 (features) x 4 (columns), wave tile 96 x 96: 6 fragment reads per 9 MFMAs
+//     (wgrad_kernel: 4 per 4), so the MFMA phase is bound by the matrix cores, not by LDS reads;
+//   * 128-byte swizzled LDS rows (wsae_mfma.h): A slice 24 KB + dense slab 48 KB per stage, two
+//     stages = 144 KB, one workgroup per CU;
+//   * the dense slab of chunk k+1 is written by LDS-DMA (global_load_lds_dwordx4, 6 per wave) while
+//     the MFMAs of chunk k run: no staging registers, no ds_write pass;
+//   * ceil(H/192) * ceil(D/384) * 2 tiles * nsplit workgroups: 256 at cfg2 with nsplit = 8, one
+//     round on the 256 CUs with every tile of one batch range on one XCD.
+// Per chunk: [entries(k+1) -> registers, DMA(k+1), zero A(k+1)] -> MFMA(k) -> barrier -> scatter(k+1)
+// -> barrier.  Every VMEM operation issued at the top of an iteration has the whole MFMA phase to land,
+// so the vmcnt(0) that __syncthreads() implies costs nothing.
+// ------------------------------------------------------------------------------------------------
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to 1 KB of LDS at the
+// wave-uniform address dst.  Inline asm rather than __builtin_amdgcn_global_load_lds: hipcc orders
+// every LDS access that follows the builtin behind s_waitcnt vmcnt(0), which would land the whole
+// slab before the MFMA phase instead of underneath it.  The asm load is invisible to hipcc's wait
+// counting, so the kernel waits for it explicitly (dma_wait) before the barrier that publishes it.
+// M0 (the DMA's LDS base) is compiler-reserved: saved and restored around the instruction.
+__device__ __forceinline__ void glds16(const void* src, uint32_t lds_byte) {
+    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(lds_byte);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_addr)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#define W2_M 192
+#define W2_N 384
+#define W2_A_BYTES (W2_M * SWZ_ROW_BYTES)
+#define W2_B_BYTES (W2_N * SWZ_ROW_BYTES)
+#define W2_STAGE (W2_A_BYTES + W2_B_BYTES)
+#define W2_THREADS 512
+
+template <typename T>
+__global__ void __launch_bounds__(W2_THREADS)
+wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid, const T* __restrict__ ent_dpre,
+              const int32_t* __restrict__ ent_off, const T* __restrict__ xT, const T* __restrict__ gT, int B, int ldT,
+              int H, int D, int nsplit, int ntm, int ntn, float* __restrict__ out, int64_t slab_stride,
+              float* __restrict__ dbe_slab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = SWZ_ROW_BYTES / (int)sizeof(T);
+    constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int split = blockIdx.x % nsplit;
+    int tile = blockIdx.x / nsplit;
+    const int which = tile / (ntm * ntn);  // 0: dW_dT (hidden, g)   1: dW_e (dpre, x_c)
+    tile -= which * ntm * ntn;
+    const int tm = tile / ntn, tn = tile % ntn;
+    const int f0 = tm * W2_M, d0 = tn * W2_N;
+    const T* Bt = which == 0 ? gT : xT;
+    const T* sv = which == 0 ? ent_hid : ent_dpre;
+    const bool do_dbe = (which == 1) && (tn == 0);
+
+    const int nchunks = (B + KT - 1) / KT;
+    const int per = (nchunks + nsplit - 1) / nsplit;
+    const int c_begin = split * per, c_end = min(nchunks, c_begin + per);
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // db_e: wave w sums the 16-row tiles w and w + 8 (12 tiles) with 16x16 MFMAs against ones
+    f32x4 rs0 = {0.f, 0.f, 0.f, 0.f}, rs1 = {0.f, 0.f, 0.f, 0.f};
+
+    // per-lane constants of the DMA: piece p = wave + 8 j covers rows 8 p .. 8 p + 7 of the dense slab
+    const int dma_r = lane >> 3, dma_s = lane & 7;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma = [&](int ck, int stage) {  // dense slab of chunk ck into stage 0 / 1
+#pragma unroll
+        for (int j = 0; j < W2_N / 8 / 8; ++j) {
+            const int piece = wave + 8 * j;
+            const int row = piece * 8 + dma_r;
+            const int c = dma_s ^ ((row >> 1) & 7);
+            const int d = min(d0 + row, D - 1);  // columns past D repeat column D-1: never stored
+            const T* src = Bt + (int64_t)d * ldT + (int64_t)ck * KT + c * EPC;
+            glds16(src, smem_lds + stage * W2_STAGE + W2_A_BYTES + piece * 1024);
+        }
+    };
+    auto zero_a = [&](char* As) {
+#pragma unroll
+        for (int c = 0; c < W2_A_BYTES / 16 / W2_THREADS; ++c)
+            *(uint4*)(As + (tid + c * W2_THREADS) * 16) = make_uint4(0, 0, 0, 0);
+    };
+    auto put = [&](char* As, uint32_t p, T v) {
+        const int f = (int)(p >> 16), bb = (int)(p & 0xFFFFu) * (int)sizeof(T);
+        *(T*)(As + swz_off(f, bb >> 4) + (bb & 15)) = v;
+    };
+
+    int e_lo = 0, e_n = 0;   // entry range of the chunk whose entries sit in registers
+    int n_lo = 0, n_n = 0;   // ... and of the chunk after it
+    uint32_t e_pos = 0;
+    T e_val = (T)0.f;
+    auto offsets = [&](int ck) {
+        const int32_t* o = ent_off + (int64_t)min(ck, nchunks - 1) * (ntm + 1) + tm;
+        n_lo = o[0];
+        n_n = o[1] - n_lo;
+    };
+    auto entries = [&](int ck) {  // entry range of ck must already sit in (n_lo, n_n)
+        e_lo = n_lo;
+        e_n = n_n;
+        const int ei = e_lo + min(tid, max(e_n - 1, 0));  // lanes past the bucket re-read its last entry
+        e_pos = ent_pos[ei];
+        e_val = sv[ei];
+        offsets(ck + 1);
+    };
+    auto scatter = [&](char* As) {
+        const int n = e_n, lo = e_lo;
+        if (tid < n) put(As, e_pos, e_val);
+        for (int e = tid + W2_THREADS; e < n; e += W2_THREADS) put(As, ent_pos[lo + e], sv[lo + e]);
+    };
+
+    if (c_begin < c_end) {
+        offsets(c_begin);
+        entries(c_begin);
+        dma(c_begin, 0);
+        zero_a(smem);
+        __syncthreads();
+        scatter(smem);
+        dma_wait();
+        __syncthreads();
+    }
+    for (int ck = c_begin; ck < c_end; ++ck) {
+        const int buf = (ck - c_begin) & 1;
+        char* cur = smem + buf * W2_STAGE;
+        char* nxt = smem + (buf ^ 1) * W2_STAGE;
+        const bool more = ck + 1 < c_end;
+        if (more) {
+            entries(ck + 1);
+            zero_a(nxt);
+            dma(ck + 1, buf ^ 1);
+        }
+        Mfma96<T>::slab(cur, cur + W2_A_BYTES, wm * 96, wn * 96, lane, acc);
+        if (do_dbe) {
+            Mfma96<T>::rowsum16(cur, wave * 16, lane, rs0);
+            if (wave < 4) Mfma96<T>::rowsum16(cur, (wave + 8) * 16, lane, rs1);
+        }
+        dma_wait();  // issued before the MFMA phase: landed long ago
+        __syncthreads();
+        if (more) scatter(nxt);
+        __syncthreads();
+    }
+
+    float* dst = out + (int64_t)split * slab_stride + (which == 0 ? (int64_t)H * D : 0);
+    const int col = lane & 31, rq = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) {
+            const int d = d0 + wn * 96 + ni * 32 + col;
+            if (d >= D) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = f0 + wm * 96 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                if (f < H) dst[(int64_t)f * D + d] = acc[mi][ni][r];
+            }
+        }
+    if (do_dbe && (lane & 15) == 0) {  // column 0 of the ones product = the row sums
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int fa = f0 + wave * 16 + 4 * (lane >> 4) + j;
+            if (fa < H) dbe_slab[(int64_t)split * H + fa] = rs0[j];
+            const int fb = f0 + (wave + 8) * 16 + 4 * (lane >> 4) + j;
+            if (wave < 4 && fb < H) dbe_slab[(int64_t)split * H + fb] = rs1[j];
+        }
     }
 }
 
@@ -353,13 +530,14 @@ static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const
     constexpr int KT = Mfma<T>::KT;
     const int nchunks = ceil_div(B, KT);
     WSAE_PROF_BEGIN(ctx, WSAE_K_BUCKET, st);
-    bucket_kernel<T><<<nchunks, 256, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, ctx->ent_pos, (T*)ctx->ent_hid,
-                                              (T*)ctx->ent_dpre, ctx->ent_off);
+    bucket_kernel<T><<<nchunks, 256, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, nt == 0 ? W2_M : TILE_M, ctx->ent_pos,
+                                              (T*)ctx->ent_hid, (T*)ctx->ent_dpre, ctx->ent_off);
     WSAE_PROF_END(ctx, WSAE_K_BUCKET, st);
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD, st);
 #define WG_ARGS ctx->ent_pos, (const T*)ctx->ent_hid, (const T*)ctx->ent_dpre, ctx->ent_off, (const T*)ctx->xT, \
                 (const T*)ctx->gT, B, ldT, ctx->H, ctx->D, nsplit, ntm, ntn, out, slab_stride, ctx->dbe_slab
-    if (nt == 3) wgrad_kernel<T, 3><<<grid, 768, 2 * 4 * TILE_LDS_BYTES, st>>>(WG_ARGS);
+    if (nt == 0) wgrad2_kernel<T><<<grid, W2_THREADS, 2 * W2_STAGE, st>>>(WG_ARGS);
+    else if (nt == 3) wgrad_kernel<T, 3><<<grid, 768, 2 * 4 * TILE_LDS_BYTES, st>>>(WG_ARGS);
     else if (nt == 2) wgrad_kernel<T, 2><<<grid, 512, 2 * 3 * TILE_LDS_BYTES, st>>>(WG_ARGS);
     else wgrad_kernel<T, 1><<<grid, 256, 2 * 2 * TILE_LDS_BYTES, st>>>(WG_ARGS);
 #undef WG_ARGS
@@ -379,8 +557,12 @@ extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void*
     const int nchunks = ceil_div(B, kt);
     // column groups per workgroup: all of D in one workgroup when D is 2 or 3 tiles wide
     const int ncol = ceil_div(D, TILE_N);
-    const int nt = (ncol % 3 == 0) ? 3 : (ncol % 2 == 0) ? 2 : 1;
-    const int ntm = ceil_div(H, TILE_M), ntn = ncol / nt;
+    // nt = 0 selects wgrad2_kernel (192 x 384 tiles) for wide inputs; WSAE_WGRAD_V1 keeps the 128-feature kernel
+    static const bool force_v1 = getenv("WSAE_WGRAD_V1") != nullptr;
+    const bool v2 = D > 256 && !force_v1;
+    const int nt = v2 ? 0 : (ncol % 3 == 0) ? 3 : (ncol % 2 == 0) ? 2 : 1;
+    const int ntm = v2 ? ceil_div(H, W2_M) : ceil_div(H, TILE_M);
+    const int ntn = v2 ? ceil_div(D, W2_N) : ncol / nt;
     const int nsplit = pick_nsplit(ctx, ntm * ntn * 2, nchunks, nt);
     const int64_t slab_stride = 2 * (int64_t)H * D;
     WSAE_REQUIRE(ntm <= BUCKET_MAX_TILES, "hidden_dim %d too large for the bucket pass (max %d)", H, BUCKET_MAX_TILES * 128);
