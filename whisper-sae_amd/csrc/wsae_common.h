@@ -91,7 +91,7 @@ struct wsae_ctx {
     void* ent_hid;        // [maxB*K] relu(value) in the contraction dtype, bucket order
     void* ent_dpre;       // [maxB*K] dpre, bucket order
     int32_t* ent_off;     // [ceil(maxB/32)][ceil(H/128)+1] bucket boundaries
-    int32_t* counters;    // small int scratch (fallback rows, dead count, resample cursors)
+    int32_t* counters;    // small int scratch (fallback rows, resample cursors; [16..) = arrival tickets, 8-byte aligned)
     int32_t* dead_list;   // [H] compacted dead feature indices (resample)
     int32_t* row_order;   // [maxB] rows sorted by error (resample)
     // ---- fused TopK (filter path) ---------------------------------------------------------------
@@ -157,6 +157,33 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 }
 
 // load one activation element as float
+// Two-level arrival ticket.  Exactly one caller per grid - the last block to arrive - gets true;
+// `payload` values (their grid sum must stay below 2^32) are added up on the way and handed to that
+// block in *total.  One thread per block calls this after the block's own work is complete.
+// 768 blocks hitting ONE address serialise in the memory-side atomic unit (~9 ns each: 7 us of a
+// 25 us kernel); here a block bumps one of TICKET_GROUPS group words and only the last arriver of a
+// group bumps the grid word, so no address sees more than max(grid / groups, groups) atomics.
+// t: 1 + TICKET_GROUPS zeroed 64-bit words, left zeroed again for the next launch.
+#define TICKET_GROUPS 32
+#define TICKET_WORDS (1 + TICKET_GROUPS)
+__device__ __forceinline__ bool grid_ticket(unsigned long long* t, unsigned payload, unsigned* total) {
+    const unsigned nblk = gridDim.x * gridDim.y;
+    const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned ngrp = nblk < TICKET_GROUPS ? nblk : TICKET_GROUPS;
+    const unsigned grp = bid % ngrp;
+    const unsigned gsz = (nblk - grp + ngrp - 1) / ngrp;
+    const unsigned long long add = (1ull << 32) | payload;
+    const unsigned long long o1 = __hip_atomic_fetch_add(t + 1 + grp, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(o1 >> 32) != gsz - 1) return false;
+    __hip_atomic_store(t + 1 + grp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long add2 = (1ull << 32) | (unsigned)((o1 + add) & 0xFFFFFFFFull);
+    const unsigned long long o2 = __hip_atomic_fetch_add(t, add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(o2 >> 32) != ngrp - 1) return false;
+    __hip_atomic_store(t, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *total = (unsigned)((o2 + add2) & 0xFFFFFFFFull);
+    return true;
+}
+
 template <int DT>
 __device__ __forceinline__ float load_act(const void* p, int64_t i) {
     if (DT == WSAE_DT_BF16) return (float)((const bf16_t*)p)[i];

@@ -31,8 +31,8 @@ __device__ __forceinline__ void decode_block_epilogue(float loss_acc, int l0_acc
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = (t == (int)gridDim.x - 1);
+        unsigned unused;
+        last_s = grid_ticket((unsigned long long*)ticket, 0u, &unused);
     }
     __syncthreads();
     if (!last_s) return;
@@ -46,7 +46,6 @@ __device__ __forceinline__ void decode_block_epilogue(float loss_acc, int l0_acc
     if (threadIdx.x == 0) {
         stats->loss = ta / ((float)B * (float)D);
         stats->l0 = tc / (float)B;
-        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
 }
 
@@ -459,7 +458,7 @@ static void launch_decode(wsae_ctx* c, const TW* WdT, const float* params, const
     const float* bpre = params + c->off[4];
     const size_t sh = (8 + 4 * (size_t)c->D) * sizeof(float);
 #define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->D, c->K, recon, dpre, c->g, last_activated, step_count, \
-                 c->part_loss, c->part_l0, c->part_dbd, c->counters, stats
+                 c->part_loss, c->part_l0, c->part_dbd, c->counters + 16 + 2 * TICKET_WORDS, stats
     if (!want_bwd)
         decode_kernel<TW, EPL, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
     else if (c->prec == WSAE_PREC_BF16)
@@ -477,7 +476,7 @@ static void launch_decode_fast(wsae_ctx* c, const TW* WdT, const float* params, 
     const float* bpre = params + c->off[4];
     const size_t sh = (8 + 5 * (size_t)c->D) * sizeof(float);
 #define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->K, recon, dpre, c->g, last_activated, step_count, \
-                 c->part_loss, c->part_l0, c->part_dbd, c->counters, stats
+                 c->part_loss, c->part_l0, c->part_dbd, c->counters + 16 + 2 * TICKET_WORDS, stats
     if (!want_bwd)
         decode_fast_kernel<TW, EPL, KJ, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
     else if (c->prec == WSAE_PREC_BF16)

@@ -217,14 +217,18 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-// wave tile 96 x 96 = 3 x 3 MFMA tiles (144 accumulator VGPRs): 6 fragment reads per 9 MFMAs
-template <typename T>
+// wave tile (32 MI) x 96 = MI x 3 MFMA tiles: MI = 3 is 144 accumulator VGPRs and 6 fragment reads
+// per 9 MFMAs (two waves per SIMD); MI = 2 is 96 VGPRs and 5 reads per 6 MFMAs (three waves per SIMD)
+template <typename T, int MI>
 struct Mfma96;
 
-template <>
-struct Mfma96<bf16_t> {
+template <int MI>
+struct Mfma96<bf16_t, MI> {
+    // between(kk) runs after the MFMAs of K step kk have been issued (kk = 0..2): the caller's
+    // LDS-DMA pieces for the next chunk go there, in the shadow of the matrix pipe
+    template <typename F>
     static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
-                                                f32x16 (&acc)[3][3]) {
+                                                f32x16 (&acc)[MI][3], F&& between) {
         const int r = lane & 31, h = lane >> 5;
         const int sw = (r >> 1) & 7;  // a_row0, b_row0 and the 32-row steps are multiples of 32: they do not change the swizzle
         const char* ap = As + (a_row0 + r) * SWZ_ROW_BYTES;
@@ -232,17 +236,17 @@ struct Mfma96<bf16_t> {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int co = ((kk * 2 + h) ^ sw) << 4;
-            bf16x8 a[3], b[3];
+            bf16x8 a[MI], b[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                a[i] = *(const bf16x8*)(ap + i * 32 * SWZ_ROW_BYTES + co);
-                b[i] = *(const bf16x8*)(bp + i * 32 * SWZ_ROW_BYTES + co);
-            }
+            for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8*)(ap + i * 32 * SWZ_ROW_BYTES + co);
 #pragma unroll
-            for (int mi = 0; mi < 3; ++mi)
+            for (int i = 0; i < 3; ++i) b[i] = *(const bf16x8*)(bp + i * 32 * SWZ_ROW_BYTES + co);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 3; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            if (kk < 3) between(kk);
         }
     }
     // row sums of the 16-row tile at row0 (+= over the chunk), every column of rs holds them
@@ -262,10 +266,11 @@ struct Mfma96<bf16_t> {
 // f32: a lane's 16-byte read holds 4 consecutive k; MFMA step j of read cc pairs element j of the
 // h = 0 lanes (k = 8 cc + j) with element j of the h = 1 lanes (k = 8 cc + 4 + j).  A and B use the
 // same k permutation, so the contraction is unchanged.
-template <>
-struct Mfma96<float> {
+template <int MI>
+struct Mfma96<float, MI> {
+    template <typename F>
     static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
-                                                f32x16 (&acc)[3][3]) {
+                                                f32x16 (&acc)[MI][3], F&& between) {
         const int r = lane & 31, h = lane >> 5;
         const int sw = (r >> 1) & 7;
         const char* ap = As + (a_row0 + r) * SWZ_ROW_BYTES;
@@ -273,19 +278,19 @@ struct Mfma96<float> {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             const int co = ((cc * 2 + h) ^ sw) << 4;
-            f32x4 a[3], b[3];
+            f32x4 a[MI], b[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                a[i] = *(const f32x4*)(ap + i * 32 * SWZ_ROW_BYTES + co);
-                b[i] = *(const f32x4*)(bp + i * 32 * SWZ_ROW_BYTES + co);
-            }
+            for (int i = 0; i < MI; ++i) a[i] = *(const f32x4*)(ap + i * 32 * SWZ_ROW_BYTES + co);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) b[i] = *(const f32x4*)(bp + i * 32 * SWZ_ROW_BYTES + co);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int mi = 0; mi < 3; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 3; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+            if (cc < 3) between(cc);
         }
     }
     static __device__ __forceinline__ void rowsum16(const char* As, int row0, int lane, f32x4& rs) {

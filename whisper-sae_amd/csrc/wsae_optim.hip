@@ -152,14 +152,9 @@ refresh_kernel(const float* __restrict__ We, float* __restrict__ WdT, const floa
     if (lane == 0) dead_s[wave] = dead;
     __syncthreads();
     if (threadIdx.x == 0) {
-        // one 64-bit atomic per block: low word accumulates the dead count, high word counts arrivals
-        unsigned long long* c64 = (unsigned long long*)(counters + 2);
-        const unsigned long long add = (1ull << 32) | (unsigned long long)(dead_s[0] + dead_s[1] + dead_s[2] + dead_s[3]);
-        const unsigned long long old = __hip_atomic_fetch_add(c64, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((old >> 32) == gridDim.x - 1) {
-            const int tot = (int)((old + add) & 0xFFFFFFFFull);
-            __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            stats->dead_count = tot;
+        unsigned tot;  // the ticket also sums the per-block dead counts
+        if (grid_ticket((unsigned long long*)(counters + 16), (unsigned)(dead_s[0] + dead_s[1] + dead_s[2] + dead_s[3]), &tot)) {
+            stats->dead_count = (int)tot;
             stats->dead_ratio = (float)tot / (float)H;
         }
     }
@@ -201,7 +196,42 @@ __device__ __forceinline__ float adam1(float p, float g, float& m, float& v, con
     return p * a.decay - a.step_size * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
 }
 
-template <bool NORMALIZE, bool SHADOW>
+// Memory-level parallelism: a wave owns ONE feature row and issues every load of it (p, g, m, v of
+// the W_e and W_dT rows, the b_e scalars: 16 float4 per lane at D = 384) before anything else; the
+// per-block prologue (norm partials -> clip coefficient, new b_pre) then runs underneath those loads.
+// NI = float4 per lane and row (D <= 256 NI).  Addresses past the row are clamped instead of
+// predicated (predicated loads sit behind exec branches and hipcc drains vmcnt(0) at each of them).
+template <int NI>
+struct RowRegs {
+    float4 p[NI], g[NI], m[NI], v[NI];
+};
+
+template <int NI>
+__device__ __forceinline__ void row_load(RowRegs<NI>& r, const float* __restrict__ P, const float* __restrict__ G,
+                                         const float* __restrict__ M, const float* __restrict__ V, int64_t base, int D,
+                                         int lane) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int64_t o = base + min(lane * 4 + 256 * i, D - 4);
+        r.p[i] = *(const float4*)(P + o);
+        r.g[i] = *(const float4*)(G + o);
+        r.m[i] = *(const float4*)(M + o);
+        r.v[i] = *(const float4*)(V + o);
+    }
+}
+
+template <int NI>
+__device__ __forceinline__ void row_adam(RowRegs<NI>& r, const AdamArgs& a, float gs) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        r.p[i].x = adam1(r.p[i].x, r.g[i].x, r.m[i].x, r.v[i].x, a, gs);
+        r.p[i].y = adam1(r.p[i].y, r.g[i].y, r.m[i].y, r.v[i].y, a, gs);
+        r.p[i].z = adam1(r.p[i].z, r.g[i].z, r.m[i].z, r.v[i].z, a, gs);
+        r.p[i].w = adam1(r.p[i].w, r.g[i].w, r.m[i].w, r.v[i].w, a, gs);
+    }
+}
+
+template <bool NORMALIZE, bool SHADOW, int NI>
 __global__ void __launch_bounds__(256)
 update_rows_kernel(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M, float* __restrict__ V,
                    int64_t oWe, int64_t oWd, int64_t oBe, int64_t oBd, int64_t oBp, int H, int D,
@@ -214,7 +244,25 @@ update_rows_kernel(float* __restrict__ P, const float* __restrict__ G, float* __
     __shared__ float red[8];
     __shared__ float gs_s;
     __shared__ int dead_s[4];
+    __shared__ int last_blk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    static_assert(REFRESH_ROWS == 4, "one row per wave");
+    const int h = blockIdx.x * REFRESH_ROWS + wave;
+    const int hc = min(h, H - 1);
+    constexpr bool BOTH = NI <= 3;  // both rows fit in registers at once (8 NI float4 per lane)
+
+    RowRegs<NI> re, rd;
+    row_load<NI>(re, P, G, M, V, oWe + (int64_t)hc * D, D, lane);
+    if (BOTH) row_load<NI>(rd, P, G, M, V, oWd + (int64_t)hc * D, D, lane);
+    float be_p = P[oBe + hc], be_g = G[oBe + hc], be_m = M[oBe + hc], be_v = V[oBe + hc];
+    int64_t la = 0, sc = 0;
+    if (last) {
+        la = last[hc];
+        sc = *step_count;
+    }
+
+    // ---- per-block prologue: clip coefficient, the NEW b_pre (every block computes it from the old
+    // state with identical arithmetic; the state itself is written once, by the last block to arrive)
     float sq = 0.f;
     for (int i = threadIdx.x; i < nparts; i += 256) sq += part_sq[i];
     const float tot = block_sum(sq, red);
@@ -230,78 +278,65 @@ update_rows_kernel(float* __restrict__ P, const float* __restrict__ G, float* __
     }
     __syncthreads();
     const float gs = gs_s;
-    // the NEW b_pre, computed by every block from the old state with identical arithmetic (the folded
-    // bias needs it); the state itself is written once, by the last block to arrive (see the end)
     for (int d = threadIdx.x; d < D; d += 256) {
         float m = M[oBp + d], v = V[oBp + d];
         bp_s[d] = adam1(P[oBp + d], G[oBp + d], m, v, a, gs);
     }
     __syncthreads();
+
     int dead = 0;
-    constexpr int RPW = REFRESH_ROWS / 4;
-    const int hbase = blockIdx.x * REFRESH_ROWS + wave * RPW;
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int h = hbase + r;
-        if (h >= H) break;
+    if (h < H) {
         // ---- W_e row: AdamW, shadow, folded-bias dot ----
+        row_adam<NI>(re, a, gs);
         float dot = 0.f;
-        for (int d = lane * 4; d < D; d += 256) {
-            const int64_t o = oWe + (int64_t)h * D + d;
-            float4 p = *(const float4*)(P + o), m = *(const float4*)(M + o), v = *(const float4*)(V + o);
-            const float4 g = *(const float4*)(G + o);
-            p.x = adam1(p.x, g.x, m.x, v.x, a, gs); p.y = adam1(p.y, g.y, m.y, v.y, a, gs);
-            p.z = adam1(p.z, g.z, m.z, v.z, a, gs); p.w = adam1(p.w, g.w, m.w, v.w, a, gs);
-            *(float4*)(P + o) = p; *(float4*)(M + o) = m; *(float4*)(V + o) = v;
-            if (SHADOW) {
-                bf16x4 e;
-                e[0] = (bf16_t)p.x; e[1] = (bf16_t)p.y; e[2] = (bf16_t)p.z; e[3] = (bf16_t)p.w;
-                *(bf16x4*)(We16 + (int64_t)h * D + d) = e;
-                const float4 bp = *(const float4*)(bp_s + d);
-                dot = fmaf((float)e[0], bp.x, dot); dot = fmaf((float)e[1], bp.y, dot);
-                dot = fmaf((float)e[2], bp.z, dot); dot = fmaf((float)e[3], bp.w, dot);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int d = lane * 4 + 256 * i;
+            if (d < D) {
+                const int64_t o = oWe + (int64_t)h * D + d;
+                *(float4*)(P + o) = re.p[i]; *(float4*)(M + o) = re.m[i]; *(float4*)(V + o) = re.v[i];
+                if (SHADOW) {
+                    bf16x4 e;
+                    e[0] = (bf16_t)re.p[i].x; e[1] = (bf16_t)re.p[i].y; e[2] = (bf16_t)re.p[i].z; e[3] = (bf16_t)re.p[i].w;
+                    *(bf16x4*)(We16 + (int64_t)h * D + d) = e;
+                    const float4 bp = *(const float4*)(bp_s + d);
+                    dot = fmaf((float)e[0], bp.x, dot); dot = fmaf((float)e[1], bp.y, dot);
+                    dot = fmaf((float)e[2], bp.z, dot); dot = fmaf((float)e[3], bp.w, dot);
+                }
             }
         }
         // ---- b_e[h] ----
-        float nbe = 0.f;
+        const float nbe = adam1(be_p, be_g, be_m, be_v, a, gs);
         if (lane == 0) {
-            float m = M[oBe + h], v = V[oBe + h];
-            nbe = adam1(P[oBe + h], G[oBe + h], m, v, a, gs);
-            P[oBe + h] = nbe; M[oBe + h] = m; V[oBe + h] = v;
+            P[oBe + h] = nbe; M[oBe + h] = be_m; V[oBe + h] = be_v;
         }
         if (SHADOW) {
             dot = wave_sum(dot);
             if (lane == 0) cfold[h] = nbe - dot;
         }
-        // ---- W_dT row: AdamW, unit norm, shadow (row kept in registers between the two passes) ----
-        float4 wd[8];
+        // ---- W_dT row: AdamW, unit norm, shadow ----
+        if (!BOTH) row_load<NI>(rd, P, G, M, V, oWd + (int64_t)h * D, D, lane);
+        row_adam<NI>(rd, a, gs);
         float s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int d = lane * 4 + 256 * i;
-            if (d < D) {
-                const int64_t o = oWd + (int64_t)h * D + d;
-                float4 p = *(const float4*)(P + o), m = *(const float4*)(M + o), v = *(const float4*)(V + o);
-                const float4 g = *(const float4*)(G + o);
-                p.x = adam1(p.x, g.x, m.x, v.x, a, gs); p.y = adam1(p.y, g.y, m.y, v.y, a, gs);
-                p.z = adam1(p.z, g.z, m.z, v.z, a, gs); p.w = adam1(p.w, g.w, m.w, v.w, a, gs);
-                *(float4*)(M + o) = m; *(float4*)(V + o) = v;
-                wd[i] = p;
+        for (int i = 0; i < NI; ++i)
+            if (lane * 4 + 256 * i < D) {
+                const float4 p = rd.p[i];
                 s2 += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
             }
-        }
         float inv = 1.f;
         if (NORMALIZE) {
             s2 = wave_sum(s2);
             inv = 1.f / fmaxf(sqrtf(s2), 1e-12f);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int d = lane * 4 + 256 * i;
             if (d < D) {
-                float4 p = wd[i];
+                const int64_t o = oWd + (int64_t)h * D + d;
+                float4 p = rd.p[i];
                 p.x *= inv; p.y *= inv; p.z *= inv; p.w *= inv;
-                *(float4*)(P + oWd + (int64_t)h * D + d) = p;
+                *(float4*)(P + o) = p; *(float4*)(M + o) = rd.m[i]; *(float4*)(V + o) = rd.v[i];
                 if (SHADOW) {
                     bf16x4 o16;
                     o16[0] = (bf16_t)p.x; o16[1] = (bf16_t)p.y; o16[2] = (bf16_t)p.z; o16[3] = (bf16_t)p.w;
@@ -309,25 +344,18 @@ update_rows_kernel(float* __restrict__ P, const float* __restrict__ G, float* __
                 }
             }
         }
-        if (last) dead += ((*step_count - last[h]) > thr) ? 1 : 0;
+        if (last) dead = ((sc - la) > thr) ? 1 : 0;
     }
     // arrival ticket (low word also sums the dead-feature count); every block's reads of the old
     // b_pre / b_d state precede its ticket, so the last arriver may overwrite that state
     if (lane == 0) dead_s[wave] = dead;
     __syncthreads();
-    __shared__ int last_blk;
     if (threadIdx.x == 0) {
-        unsigned long long* c64 = (unsigned long long*)(counters + 2);
-        const unsigned long long add = (1ull << 32) | (unsigned long long)(dead_s[0] + dead_s[1] + dead_s[2] + dead_s[3]);
-        const unsigned long long old = __hip_atomic_fetch_add(c64, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_blk = (old >> 32) == gridDim.x - 1;
-        if (last_blk) {
-            __hip_atomic_store(c64, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (last && stats) {
-                const int t = (int)((old + add) & 0xFFFFFFFFull);
-                stats->dead_count = t;
-                stats->dead_ratio = (float)t / (float)H;
-            }
+        unsigned t = 0;
+        last_blk = grid_ticket((unsigned long long*)(counters + 16), (unsigned)(dead_s[0] + dead_s[1] + dead_s[2] + dead_s[3]), &t);
+        if (last_blk && last && stats) {
+            stats->dead_count = (int)t;
+            stats->dead_ratio = (float)t / (float)H;
         }
     }
     __syncthreads();
@@ -340,6 +368,19 @@ update_rows_kernel(float* __restrict__ P, const float* __restrict__ G, float* __
         const float nd = adam1(P[oBd + d], G[oBd + d], md, vd, a, gs);
         P[oBd + d] = nd; M[oBd + d] = md; V[oBd + d] = vd;
     }
+}
+
+template <int NI>
+static void launch_update_rows(bool normalize, bool shadow, int nb, size_t sh, hipStream_t st, float* P, const float* G,
+                               float* M, float* V, wsae_ctx* ctx, int nparts, const AdamArgs& a, const int64_t* last,
+                               const int64_t* step_count, int64_t thr, wsae_stats* stats) {
+#define UP_ARGS P, G, M, V, ctx->off[0], ctx->off[1], ctx->off[2], ctx->off[3], ctx->off[4], ctx->H, ctx->D, ctx->part_sq, \
+                nparts, a, ctx->We_bf16, ctx->WdT_bf16, ctx->c_fold, last, step_count, thr, ctx->counters, stats
+    if (normalize && shadow) update_rows_kernel<true, true, NI><<<nb, 256, sh, st>>>(UP_ARGS);
+    else if (normalize) update_rows_kernel<true, false, NI><<<nb, 256, sh, st>>>(UP_ARGS);
+    else if (shadow) update_rows_kernel<false, true, NI><<<nb, 256, sh, st>>>(UP_ARGS);
+    else update_rows_kernel<false, false, NI><<<nb, 256, sh, st>>>(UP_ARGS);
+#undef UP_ARGS
 }
 
 extern "C" int wsae_normalize_decoder(wsae_ctx* ctx, float* params, void* stream) {
@@ -383,16 +424,18 @@ extern "C" int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads,
     const int nb = ceil_div(ctx->H, REFRESH_ROWS);
     const size_t sh = (size_t)ctx->D * sizeof(float);
     const bool shadow = ctx->prec == WSAE_PREC_BF16;
-#define UP_ARGS params, grads, exp_avg, exp_avg_sq, ctx->off[0], ctx->off[1], ctx->off[2], ctx->off[3], ctx->off[4], ctx->H, \
-                ctx->D, ctx->part_sq, nparts, a, ctx->We_bf16, ctx->WdT_bf16, ctx->c_fold, last_activated, step_count, \
-                dead_threshold, ctx->counters, stats
+    WSAE_REQUIRE(ctx->D % 4 == 0 && ctx->D >= 4 && ctx->D <= 2048, "wsae_adamw_step: input_dim %d not in [4, 2048] / 4", ctx->D);
+    const int ni = ceil_div(ctx->D, 256);
     WSAE_PROF_BEGIN(ctx, WSAE_K_ADAMW, st);
-    if (normalize_decoder && shadow) update_rows_kernel<true, true><<<nb, 256, sh, st>>>(UP_ARGS);
-    else if (normalize_decoder) update_rows_kernel<true, false><<<nb, 256, sh, st>>>(UP_ARGS);
-    else if (shadow) update_rows_kernel<false, true><<<nb, 256, sh, st>>>(UP_ARGS);
-    else update_rows_kernel<false, false><<<nb, 256, sh, st>>>(UP_ARGS);
+#define UP_CALL(NI_) launch_update_rows<NI_>(normalize_decoder != 0, shadow, nb, sh, st, params, grads, exp_avg, exp_avg_sq, \
+                                            ctx, nparts, a, last_activated, step_count, dead_threshold, stats)
+    if (ni <= 1) UP_CALL(1);
+    else if (ni == 2) UP_CALL(2);
+    else if (ni == 3) UP_CALL(3);
+    else if (ni == 4) UP_CALL(4);
+    else UP_CALL(8);
+#undef UP_CALL
     WSAE_PROF_END(ctx, WSAE_K_ADAMW, st);
-#undef UP_ARGS
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;
 }

@@ -238,7 +238,10 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 #define W2_A_BYTES (W2_M * SWZ_ROW_BYTES)
 #define W2_B_BYTES (W2_N * SWZ_ROW_BYTES)
 #define W2_STAGE (W2_A_BYTES + W2_B_BYTES)
-#define W2_THREADS 512
+#define W2_MI 3  // MFMA row tiles per wave: 2 -> 12 waves (3 x 4), 3 -> 8 waves (2 x 4)
+#define W2_WAVES (W2_M / (32 * W2_MI) * 4)
+#define W2_THREADS (64 * W2_WAVES)
+#define W2_PIECES (W2_N / 8 / W2_WAVES)  // 1 KB LDS-DMA pieces per wave and chunk
 
 template <typename T>
 __global__ void __launch_bounds__(W2_THREADS)
@@ -265,23 +268,24 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
     const int per = (nchunks + nsplit - 1) / nsplit;
     const int c_begin = split * per, c_end = min(nchunks, c_begin + per);
 
-    f32x16 acc[3][3];
+    f32x16 acc[W2_MI][3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < W2_MI; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // db_e: wave w sums the 16-row tiles w and w + 8 (12 tiles) with 16x16 MFMAs against ones
+    // db_e: wave w sums the 16-row tiles w and w + W2_WAVES (12 tiles) with 16x16 MFMAs against ones
     f32x4 rs0 = {0.f, 0.f, 0.f, 0.f}, rs1 = {0.f, 0.f, 0.f, 0.f};
 
     // per-lane constants of the DMA: piece p = wave + 8 j covers rows 8 p .. 8 p + 7 of the dense slab
     const int dma_r = lane >> 3, dma_s = lane & 7;
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto dma = [&](int ck, int stage) {  // dense slab of chunk ck into stage 0 / 1
+    // dense slab of chunk ck into stage 0 / 1: half of this wave's pieces per call (j0 = 0 or W2_PIECES / 2)
+    auto dma3 = [&](int ck, int stage, int j0) {
 #pragma unroll
-        for (int j = 0; j < W2_N / 8 / 8; ++j) {
-            const int piece = wave + 8 * j;
+        for (int j = j0; j < j0 + W2_PIECES / 2; ++j) {
+            const int piece = wave + W2_WAVES * j;
             const int row = piece * 8 + dma_r;
             const int c = dma_s ^ ((row >> 1) & 7);
             const int d = min(d0 + row, D - 1);  // columns past D repeat column D-1: never stored
@@ -289,19 +293,17 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
             glds16(src, smem_lds + stage * W2_STAGE + W2_A_BYTES + piece * 1024);
         }
     };
-    auto zero_a = [&](char* As) {
-#pragma unroll
-        for (int c = 0; c < W2_A_BYTES / 16 / W2_THREADS; ++c)
-            *(uint4*)(As + (tid + c * W2_THREADS) * 16) = make_uint4(0, 0, 0, 0);
-    };
     auto put = [&](char* As, uint32_t p, T v) {
         const int f = (int)(p >> 16), bb = (int)(p & 0xFFFFu) * (int)sizeof(T);
         *(T*)(As + swz_off(f, bb >> 4) + (bb & 15)) = v;
     };
 
-    int e_lo = 0, e_n = 0;   // entry range of the chunk whose entries sit in registers
-    int n_lo = 0, n_n = 0;   // ... and of the chunk after it
-    uint32_t e_pos = 0;
+    // The sparse slice is never re-zeroed: after the MFMAs of a chunk its entries are overwritten with
+    // zeros again (un-scatter, <= 1 two-byte store per thread) instead of clearing 24 KB per chunk.
+    int e_lo = 0, e_n = 0;   // entry range of the chunk whose entries sit in registers (the NEXT chunk)
+    int p_lo = 0, p_n = 0;   // ... of the chunk the MFMAs are working on (for the un-scatter)
+    int n_lo = 0, n_n = 0;   // ... and of the chunk after e (offsets run one chunk ahead of the entries)
+    uint32_t e_pos = 0, p_pos = 0;
     T e_val = (T)0.f;
     auto offsets = [&](int ck) {
         const int32_t* o = ent_off + (int64_t)min(ck, nchunks - 1) * (ntm + 1) + tm;
@@ -309,6 +311,7 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
         n_n = o[1] - n_lo;
     };
     auto entries = [&](int ck) {  // entry range of ck must already sit in (n_lo, n_n)
+        p_lo = e_lo; p_n = e_n; p_pos = e_pos;
         e_lo = n_lo;
         e_n = n_n;
         const int ei = e_lo + min(tid, max(e_n - 1, 0));  // lanes past the bucket re-read its last entry
@@ -321,12 +324,21 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
         if (tid < n) put(As, e_pos, e_val);
         for (int e = tid + W2_THREADS; e < n; e += W2_THREADS) put(As, ent_pos[lo + e], sv[lo + e]);
     };
+    auto unscatter = [&](char* As, int lo, int n, uint32_t pos) {
+        if (tid < n) put(As, pos, (T)0.f);
+        for (int e = tid + W2_THREADS; e < n; e += W2_THREADS) put(As, ent_pos[lo + e], (T)0.f);
+    };
 
     if (c_begin < c_end) {
         offsets(c_begin);
         entries(c_begin);
-        dma(c_begin, 0);
-        zero_a(smem);
+        dma3(c_begin, 0, 0);
+        dma3(c_begin, 0, W2_PIECES / 2);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int c = 0; c < W2_A_BYTES / 16 / W2_THREADS; ++c)
+                *(uint4*)(smem + st * W2_STAGE + (tid + c * W2_THREADS) * 16) = make_uint4(0, 0, 0, 0);
         __syncthreads();
         scatter(smem);
         dma_wait();
@@ -337,33 +349,35 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
         char* cur = smem + buf * W2_STAGE;
         char* nxt = smem + (buf ^ 1) * W2_STAGE;
         const bool more = ck + 1 < c_end;
-        if (more) {
-            entries(ck + 1);
-            zero_a(nxt);
-            dma(ck + 1, buf ^ 1);
-        }
-        Mfma96<T>::slab(cur, cur + W2_A_BYTES, wm * 96, wn * 96, lane, acc);
+        entries(min(ck + 1, c_end - 1));  // (the last iteration re-reads its own chunk: keeps p_* = this chunk)
+        // (one call site: two copies of the MFMA phase made hipcc double the accumulators and spill)
+        Mfma96<T, W2_MI>::slab(cur, cur + W2_A_BYTES, wm * 32 * W2_MI, wn * 96, lane, acc, [&](int kk) {
+            if (more && kk < 2) dma3(ck + 1, buf ^ 1, kk * (W2_PIECES / 2));  // >= half a phase to land
+        });
         if (do_dbe) {
-            Mfma96<T>::rowsum16(cur, wave * 16, lane, rs0);
-            if (wave < 4) Mfma96<T>::rowsum16(cur, (wave + 8) * 16, lane, rs1);
+            Mfma96<T, W2_MI>::rowsum16(cur, wave * 16, lane, rs0);
+            if (wave + W2_WAVES < W2_M / 16) Mfma96<T, W2_MI>::rowsum16(cur, (wave + W2_WAVES) * 16, lane, rs1);
         }
-        dma_wait();  // issued before the MFMA phase: landed long ago
+        dma_wait();  // issued during the MFMA phase of a 2 us chunk: landed
         __syncthreads();
-        if (more) scatter(nxt);
+        if (more) {
+            unscatter(cur, p_lo, p_n, p_pos);
+            scatter(nxt);
+        }
         __syncthreads();
     }
 
     float* dst = out + (int64_t)split * slab_stride + (which == 0 ? (int64_t)H * D : 0);
     const int col = lane & 31, rq = lane >> 5;
 #pragma unroll
-    for (int mi = 0; mi < 3; ++mi)
+    for (int mi = 0; mi < W2_MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 3; ++ni) {
             const int d = d0 + wn * 96 + ni * 32 + col;
             if (d >= D) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int f = f0 + wm * 96 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                const int f = f0 + wm * 32 * W2_MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
                 if (f < H) dst[(int64_t)f * D + d] = acc[mi][ni][r];
             }
         }
@@ -372,8 +386,8 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
         for (int j = 0; j < 4; ++j) {
             const int fa = f0 + wave * 16 + 4 * (lane >> 4) + j;
             if (fa < H) dbe_slab[(int64_t)split * H + fa] = rs0[j];
-            const int fb = f0 + (wave + 8) * 16 + 4 * (lane >> 4) + j;
-            if (wave < 4 && fb < H) dbe_slab[(int64_t)split * H + fb] = rs1[j];
+            const int fb = f0 + (wave + W2_WAVES) * 16 + 4 * (lane >> 4) + j;
+            if (wave + W2_WAVES < W2_M / 16 && fb < H) dbe_slab[(int64_t)split * H + fb] = rs1[j];
         }
     }
 }
