@@ -392,125 +392,144 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
     }
 }
 
-// grads[W parts] = sum over splits of the slabs (fixed order); db_e likewise; in BF16 mode the
-// rank-1 correction of the folded pre-bias is applied on the way:
-//   dW_e[h,:] -= db_e[h] * b_pre      (the MFMA contraction saw raw x, not x - b_pre)
-template <bool FOLD>
-__global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, const float* __restrict__ dbe_slab, int nsplit,
-                    const float* __restrict__ bpre, float* __restrict__ grads, float* __restrict__ dbe_out, int H, int D,
-                    float* __restrict__ part_sq) {
-    __shared__ float red[8];
-    float sq = 0.f;  // sum of squares of everything this block writes (global-norm partial)
-    const int64_t n4 = (int64_t)2 * H * D / 4;
-    const int64_t hd4 = (int64_t)H * D / 4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 a = ((const float4*)slabs)[i];
-        for (int s = 1; s < nsplit; ++s) {
-            const float4 b = ((const float4*)(slabs + s * slab_stride))[i];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
-        if (i < hd4) {  // dW_e segment
-            const int64_t e = i * 4;
-            const int h = (int)(e / D), d = (int)(e - (int64_t)h * D);
-            float be = 0.f;
-            for (int s = 0; s < nsplit; ++s) be += dbe_slab[(int64_t)s * H + h];
-            if (d == 0) {
-                dbe_out[h] = be;
-                sq = fmaf(be, be, sq);
-            }
-            if (FOLD) {
-                const float4 bp = *(const float4*)(bpre + d);
-                a.x -= be * bp.x; a.y -= be * bp.y; a.z -= be * bp.z; a.w -= be * bp.w;
-            }
-        }
-        ((float4*)grads)[i] = a;
-        sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-    }
-    const float t = block_sum(sq, red);
-    if (threadIdx.x == 0) part_sq[blockIdx.x] = t;
-}
-
-// blocks [0, nblk_h): db_pre partials  part[blk][d] = sum_{h in blk's 128 rows} db_e[h] * W[h][d]
-// blocks [nblk_h, nblk_h + 64): level-1 reduction of the decode launch's column sums of g,
-//   dbd2[j][d] = sum over decode blocks i = j, j+64, ... of part_dbd[i][d]      (no atomics anywhere)
-// Loads are issued 32 (resp. 16) at a time: a one-at-a-time loop here is pure L2 latency.
+// ------------------------------------------------------------------------------------------------
+// grad_finish_kernel: everything between the split-K contraction and the optimizer, in ONE launch of
+// three kinds of blocks (they share nothing, so they share the launch instead of queueing behind each
+// other's tails):
+//   [0, nrb)               grads[W parts] = sum over splits of the slabs (fixed order); db_e likewise; in
+//                          BF16 mode the rank-1 correction of the folded pre-bias on the way:
+//                              dW_e[h,:] -= db_e[h] * b_pre   (the MFMA contraction saw raw x, not x - b_pre)
+//                          and the block's share of the global-norm partials;
+//   [nrb, nrb + nblk_h)    db_pre partials  part[blk][d] = sum_{h in blk's 128 rows} db_e[h] * W_e[h][d]
+//                          (db_e re-summed from the split slabs, so these blocks do not wait for the first kind);
+//   [.., + DBD_L1)         level-1 reduction of the decode launch's column sums of g,
+//                          dbd2[j][d] = sum over decode blocks i = j, j + DBD_L1, ... of part_dbd[i][d].
+// The last block to arrive (two-level ticket) finishes the biases: db_d = sum of the level-1 rows,
+// db_pre = db_d - sum of the partial rows, and their norm partial.  Hand-off as in the decode epilogue:
+// the partial rows are agent-scope (write-through) atomic stores drained with vmcnt(0) before the ticket
+// and read back with agent-scope atomic loads.  No float atomics anywhere: every sum has a fixed order.
+// Loads are issued in batches: a one-at-a-time loop here is pure L2 latency.
+// ------------------------------------------------------------------------------------------------
 #define DBPRE_ROWS 128
-#define DBD_L1 64
-template <typename TW>
+#define DBD_L1 16
+template <typename TW, bool FOLD>
 __global__ void __launch_bounds__(256)
-dbpre_partial_kernel(const TW* __restrict__ W, const float* __restrict__ dbe, float* __restrict__ part, int H, int D,
-                     int nblk_h, const float* __restrict__ part_dbd, int n_dec, float* __restrict__ dbd2) {
-    if ((int)blockIdx.x >= nblk_h) {
-        const int j = blockIdx.x - nblk_h;
-        for (int d = threadIdx.x; d < D; d += 256) {
-            float v[WSAE_MAX_PARTIALS / DBD_L1];
-#pragma unroll
-            for (int t = 0; t < WSAE_MAX_PARTIALS / DBD_L1; ++t) {
-                const int i = j + DBD_L1 * t;
-                v[t] = i < n_dec ? part_dbd[(int64_t)i * D + d] : 0.f;
-            }
-            float a = 0.f;
-#pragma unroll
-            for (int t = 0; t < WSAE_MAX_PARTIALS / DBD_L1; ++t) a += v[t];
-            dbd2[(int64_t)j * D + d] = a;
-        }
-        return;
-    }
+grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const float* __restrict__ dbe_slab, int nsplit,
+                   const float* __restrict__ bpre, float* __restrict__ grads, float* __restrict__ dbe_out, int H, int D,
+                   float* __restrict__ part_sq, int nrb, const TW* __restrict__ W, float* __restrict__ part, int nblk_h,
+                   const float* __restrict__ part_dbd, int n_dec, float* __restrict__ dbd2, float* __restrict__ dbd_out,
+                   float* __restrict__ dbpre_out, unsigned long long* __restrict__ ticket) {
+    __shared__ float red[8];
     __shared__ float e_s[DBPRE_ROWS];
-    const int h0 = blockIdx.x * DBPRE_ROWS;
-    if (threadIdx.x < DBPRE_ROWS) e_s[threadIdx.x] = (h0 + (int)threadIdx.x < H) ? dbe[h0 + threadIdx.x] : 0.f;
-    __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256) {
-        float a = 0.f;
-        for (int r0 = 0; r0 < DBPRE_ROWS; r0 += 32) {
-            float w[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) w[i] = (float)W[(int64_t)min(h0 + r0 + i, H - 1) * D + d];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) a = fmaf(e_s[r0 + i], w[i], a);
+    __shared__ int last_s;
+    // the few latency-bound blocks (kinds two and three) take the first block ids so that they start
+    // first and run under the streaming blocks instead of forming the tail of the launch
+    const int tid = threadIdx.x;
+    const int nlat = nblk_h + DBD_L1;
+    const int bid = (int)blockIdx.x >= nlat ? (int)blockIdx.x - nlat : nrb + (int)blockIdx.x;
+    if (bid < nrb) {
+        float sq = 0.f;  // sum of squares of everything this block writes (global-norm partial)
+        const int64_t n4 = (int64_t)2 * H * D / 4;
+        const int64_t hd4 = (int64_t)H * D / 4;
+        for (int64_t i = (int64_t)bid * 256 + tid; i < n4; i += (int64_t)nrb * 256) {
+            float4 a = ((const float4*)slabs)[i];
+            for (int s = 1; s < nsplit; ++s) {
+                const float4 b = ((const float4*)(slabs + s * slab_stride))[i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            if (i < hd4) {  // dW_e segment
+                const int64_t e = i * 4;
+                const int h = (int)(e / D), d = (int)(e - (int64_t)h * D);
+                float be = 0.f;
+                for (int s = 0; s < nsplit; ++s) be += dbe_slab[(int64_t)s * H + h];
+                if (d == 0) {
+                    dbe_out[h] = be;
+                    sq = fmaf(be, be, sq);
+                }
+                if (FOLD) {
+                    const float4 bp = *(const float4*)(bpre + d);
+                    a.x -= be * bp.x; a.y -= be * bp.y; a.z -= be * bp.z; a.w -= be * bp.w;
+                }
+            }
+            ((float4*)grads)[i] = a;
+            sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
         }
-        part[(int64_t)blockIdx.x * D + d] = a;
+        const float t = block_sum(sq, red);
+        if (tid == 0) part_sq[bid] = t;
+    } else if (bid < nrb + nblk_h) {
+        const int blk = bid - nrb;
+        const int h0 = blk * DBPRE_ROWS;
+        if (tid < DBPRE_ROWS) {
+            float be = 0.f;
+            if (h0 + tid < H)
+                for (int s = 0; s < nsplit; ++s) be += dbe_slab[(int64_t)s * H + h0 + tid];  // same order as above
+            e_s[tid] = be;
+        }
+        __syncthreads();
+        for (int d = tid; d < D; d += 256) {
+            float a = 0.f;
+            for (int r0 = 0; r0 < DBPRE_ROWS; r0 += 32) {
+                float w[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) w[i] = (float)W[(int64_t)min(h0 + r0 + i, H - 1) * D + d];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) a = fmaf(e_s[r0 + i], w[i], a);
+            }
+            __hip_atomic_store(part + (int64_t)blk * D + d, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        const int j = bid - nrb - nblk_h;
+        for (int d = tid; d < D; d += 256) {
+            float a = 0.f;
+            for (int t0 = 0; t0 < WSAE_MAX_PARTIALS / DBD_L1; t0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int i = j + DBD_L1 * (t0 + t);
+                    v[t] = i < n_dec ? part_dbd[(int64_t)min(i, n_dec - 1) * D + d] : 0.f;
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) a += v[t];
+            }
+            __hip_atomic_store(dbd2 + (int64_t)j * D + d, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-}
-
-// db_d = sum of the 64 level-1 rows; db_pre = db_d - sum_blk part[blk]; plus their share of the
-// global-norm partials (part_sq[sq_base + blockIdx.x]).  4 thread groups split the partial rows.
-__global__ void __launch_bounds__(256) bias_finish_kernel(const float* __restrict__ dbd2, const float* __restrict__ part,
-                                                          int nblk, float* __restrict__ dbd, float* __restrict__ dbpre,
-                                                          int D, float* __restrict__ part_sq, int sq_base) {
-    __shared__ float red[2][4][64];
-    __shared__ float red2[8];
-    const int dl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int d = blockIdx.x * 64 + dl;
-    float a = 0.f, s = 0.f;
-    if (d < D) {
-        for (int b0 = grp * 8; b0 < nblk; b0 += 32) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        unsigned unused;
+        last_s = grid_ticket(ticket, 0u, &unused);
+    }
+    __syncthreads();
+    if (!last_s) return;
+    float sq = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        float sd = 0.f, sp = 0.f;
+        {
+            float v[DBD_L1];
+#pragma unroll
+            for (int i = 0; i < DBD_L1; ++i)
+                v[i] = __hip_atomic_load(dbd2 + (int64_t)i * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < DBD_L1; ++i) sd += v[i];
+        }
+        for (int b0 = 0; b0 < nblk_h; b0 += 8) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (b0 + i < nblk) ? part[(int64_t)(b0 + i) * D + d] : 0.f;
+            for (int i = 0; i < 8; ++i)
+                v[i] = (b0 + i < nblk_h) ? __hip_atomic_load(part + (int64_t)min(b0 + i, nblk_h - 1) * D + d,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                         : 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a += v[i];
+            for (int i = 0; i < 8; ++i) sp += v[i];
         }
-        float v[DBD_L1 / 4];
-#pragma unroll
-        for (int i = 0; i < DBD_L1 / 4; ++i) v[i] = dbd2[(int64_t)(grp * (DBD_L1 / 4) + i) * D + d];
-#pragma unroll
-        for (int i = 0; i < DBD_L1 / 4; ++i) s += v[i];
+        const float p = sd - sp;
+        dbd_out[d] = sd;
+        dbpre_out[d] = p;
+        sq += sd * sd + p * p;
     }
-    red[0][grp][dl] = a;
-    red[1][grp][dl] = s;
-    __syncthreads();
-    float sq = 0.f;
-    if (grp == 0 && d < D) {
-        const float sd = red[1][0][dl] + red[1][1][dl] + red[1][2][dl] + red[1][3][dl];
-        const float p = sd - (red[0][0][dl] + red[0][1][dl] + red[0][2][dl] + red[0][3][dl]);
-        dbd[d] = sd;
-        dbpre[d] = p;
-        sq = sd * sd + p * p;
-    }
-    const float t = block_sum(sq, red2);
-    if (threadIdx.x == 0) part_sq[sq_base + blockIdx.x] = t;
+    const float t = block_sum(sq, red);
+    if (tid == 0) part_sq[nrb] = t;
 }
 
 // Split-K factor.  A workgroup walks ceil(nchunks / nsplit) batch chunks and the grid runs in
@@ -590,30 +609,20 @@ extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void*
 
     float* dbe = grads + ctx->off[2];
     const float* bpre = params + ctx->off[4];
-    const int nrb = (int)min((int64_t)WSAE_MAX_PARTIALS, ceil_div64(slab_stride / 4, 256));
+    const int nrb = (int)min((int64_t)WSAE_MAX_PARTIALS - 1, ceil_div64(slab_stride / 4, 256));
+    const int nblk = ceil_div(H, DBPRE_ROWS);
+    unsigned long long* ticket = (unsigned long long*)(ctx->counters + 16 + 4 * TICKET_WORDS);
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD_REDUCE, st);
+#define GF_ARGS out, slab_stride, ctx->dbe_slab, nsplit, bpre, grads, dbe, H, D, ctx->part_sq, nrb
+#define GF_TAIL ctx->dbpre_part, nblk, ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2, grads + ctx->off[3], grads + ctx->off[4], ticket
     if (ctx->prec == WSAE_PREC_BF16)
-        wgrad_reduce_kernel<true><<<nrb, 256, 0, st>>>(out, slab_stride, ctx->dbe_slab, nsplit, bpre, grads, dbe, H, D,
-                                                       ctx->part_sq);
+        grad_finish_kernel<bf16_t, true><<<nrb + nblk + DBD_L1, 256, 0, st>>>(GF_ARGS, (const bf16_t*)ctx->We_bf16, GF_TAIL);
     else
-        wgrad_reduce_kernel<false><<<nrb, 256, 0, st>>>(out, slab_stride, ctx->dbe_slab, nsplit, bpre, grads, dbe, H, D,
-                                                        ctx->part_sq);
+        grad_finish_kernel<float, false><<<nrb + nblk + DBD_L1, 256, 0, st>>>(GF_ARGS, params + ctx->off[0], GF_TAIL);
+#undef GF_ARGS
+#undef GF_TAIL
     WSAE_PROF_END(ctx, WSAE_K_WGRAD_REDUCE, st);
     WSAE_LAUNCH_CHECK();
-
-    const int nblk = ceil_div(H, DBPRE_ROWS);
-    const int nfin = ceil_div(D, 64);
-    WSAE_PROF_BEGIN(ctx, WSAE_K_BIAS_GRADS, st);
-    if (ctx->prec == WSAE_PREC_BF16)
-        dbpre_partial_kernel<bf16_t><<<nblk + DBD_L1, 256, 0, st>>>(ctx->We_bf16, dbe, ctx->dbpre_part, H, D, nblk,
-                                                                ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2);
-    else
-        dbpre_partial_kernel<float><<<nblk + DBD_L1, 256, 0, st>>>(params + ctx->off[0], dbe, ctx->dbpre_part, H, D, nblk,
-                                                               ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2);
-    bias_finish_kernel<<<nfin, 256, 0, st>>>(ctx->dbd2, ctx->dbpre_part, nblk, grads + ctx->off[3], grads + ctx->off[4],
-                                             D, ctx->part_sq, nrb);
-    WSAE_PROF_END(ctx, WSAE_K_BIAS_GRADS, st);
-    WSAE_LAUNCH_CHECK();
-    ctx->n_sq_parts = nrb + nfin;  // wsae_adamw_step(norm_from_wgrad = 1) sums these
+    ctx->n_sq_parts = nrb + 1;  // wsae_adamw_step(norm_from_wgrad = 1) sums these
     return WSAE_OK;
 }
