@@ -416,39 +416,6 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
     decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, part_loss, part_l0, part_dbd, ticket, stats);
 }
 
-// g [B][D] f32 -> gT [D][ldT] in the contraction dtype, zero-padded beyond column B.
-// 64 x 64 tiles through LDS; 16-byte reads along d, 8/16-byte packed writes along b.
-template <typename T>
-__global__ void __launch_bounds__(256) transpose_g_kernel(const float* __restrict__ g, T* __restrict__ gT, int B, int D,
-                                                          int ldT) {
-    __shared__ float tile[64][65];
-    const int b0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
-    const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int bl = r16 + 16 * p, b = b0 + bl, d = d0 + 4 * q;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b < B && d < D) v = *(const float4*)(g + (int64_t)b * D + d);
-        tile[bl][4 * q] = v.x; tile[bl][4 * q + 1] = v.y; tile[bl][4 * q + 2] = v.z; tile[bl][4 * q + 3] = v.w;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int dl = r16 + 16 * p, d = d0 + dl, b = b0 + 4 * q;
-        if (d < D && b < ldT) {
-            if (sizeof(T) == 2) {
-                bf16x4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (bf16_t)tile[4 * q + i][dl];
-                *(bf16x4*)(gT + (int64_t)d * ldT + b) = o;
-            } else {
-                *(float4*)(gT + (int64_t)d * ldT + b) =
-                    make_float4(tile[4 * q][dl], tile[4 * q + 1][dl], tile[4 * q + 2][dl], tile[4 * q + 3][dl]);
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 template <typename TW, int EPL, int XDT>
 static void launch_decode(wsae_ctx* c, const TW* WdT, const float* params, const void* x, const int32_t* rows,
@@ -551,17 +518,7 @@ extern "C" int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* 
     WSAE_PROF_END(ctx, WSAE_K_DECODE, st);
     WSAE_LAUNCH_CHECK();
     ctx->n_dec_blocks = nblk;
-    if (want_bwd) {
-        const int ldT = (B + 127) / 128 * 128;
-        dim3 tg(ceil_div(ldT, 64), ceil_div(ctx->D, 64));
-        WSAE_PROF_BEGIN(ctx, WSAE_K_TRANSPOSE_G, st);
-        if (ctx->prec == WSAE_PREC_BF16)
-            transpose_g_kernel<bf16_t><<<tg, 256, 0, st>>>(ctx->g, (bf16_t*)ctx->gT, B, ctx->D, ldT);
-        else
-            transpose_g_kernel<float><<<tg, 256, 0, st>>>(ctx->g, (float*)ctx->gT, B, ctx->D, ldT);
-        WSAE_PROF_END(ctx, WSAE_K_TRANSPOSE_G, st);
-        WSAE_LAUNCH_CHECK();
-    }
+    // (g stays row-major in ctx->g; wsae_weight_grads transposes it in its bucket launch)
     return WSAE_OK;
 }
 

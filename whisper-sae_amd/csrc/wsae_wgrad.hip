@@ -23,7 +23,7 @@
 #include "wsae_mfma.h"
 
 // ------------------------------------------------------------------------------------------------
-// bucket_kernel: per KT-row chunk, counting-sort the chunk's KT*K compact entries by tw-feature tile
+// bucket_kernel, blocks [0, nchunks): per KT-row chunk, counting-sort the chunk's KT*K compact entries by tw-feature tile
 // (tw = 128 for wgrad_kernel, 192 for wgrad2_kernel).
 //   ent_off[chunk][t] .. ent_off[chunk][t+1] : positions (in the flat sorted arrays) of the entries of
 //   tile t;  ent_pos = (feature - t * tw) << 16 | row-in-chunk;  ent_hid = relu(value), ent_dpre = dpre.
@@ -36,11 +36,46 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 bucket_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, const float* __restrict__ dpre, int B,
               int K, int ntiles, int tw, uint32_t* __restrict__ ent_pos, T* __restrict__ ent_hid, T* __restrict__ ent_dpre,
-              int32_t* __restrict__ ent_off) {
-    __shared__ int cnt[BUCKET_MAX_TILES];
-    __shared__ int cur[BUCKET_MAX_TILES];
+              int32_t* __restrict__ ent_off, int nchunks, const float* __restrict__ g, T* __restrict__ gT, int D, int ldT) {
+    __shared__ __attribute__((aligned(16))) char sm[64 * 65 * 4];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= nchunks) {
+        // ---- second kind of block: g [B][D] f32 -> gT [D][ldT] in the contraction dtype, zero-padded
+        // beyond column B.  64 x 64 tiles through LDS; 16-byte reads along d, 8/16-byte writes along b.
+        float (*tile)[65] = (float (*)[65])sm;
+        const int t = blockIdx.x - nchunks;
+        const int ntb = ldT / 64;
+        const int b0 = (t % ntb) * 64, d0 = (t / ntb) * 64;
+        const int q = tid & 15, r16 = tid >> 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int bl = r16 + 16 * p, b = b0 + bl, d = d0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < B && d < D) v = *(const float4*)(g + (int64_t)b * D + d);
+            tile[bl][4 * q] = v.x; tile[bl][4 * q + 1] = v.y; tile[bl][4 * q + 2] = v.z; tile[bl][4 * q + 3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int dl = r16 + 16 * p, d = d0 + dl, b = b0 + 4 * q;
+            if (d < D && b < ldT) {
+                if (sizeof(T) == 2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (bf16_t)tile[4 * q + i][dl];
+                    *(bf16x4*)(gT + (int64_t)d * ldT + b) = o;
+                } else {
+                    *(float4*)(gT + (int64_t)d * ldT + b) =
+                        make_float4(tile[4 * q][dl], tile[4 * q + 1][dl], tile[4 * q + 2][dl], tile[4 * q + 3][dl]);
+                }
+            }
+        }
+        return;
+    }
+    int* cnt = (int*)sm;
+    int* cur = cnt + BUCKET_MAX_TILES;
     constexpr int KT = Mfma<T>::KT;
-    const int chunk = blockIdx.x, tid = threadIdx.x;
+    const int chunk = blockIdx.x;
     const int b0 = chunk * KT;
     const int nent = min(KT, B - b0) * K;
     const int64_t base = (int64_t)b0 * K;
@@ -563,8 +598,11 @@ static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const
     constexpr int KT = Mfma<T>::KT;
     const int nchunks = ceil_div(B, KT);
     WSAE_PROF_BEGIN(ctx, WSAE_K_BUCKET, st);
-    bucket_kernel<T><<<nchunks, 256, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, nt == 0 ? W2_M : TILE_M, ctx->ent_pos,
-                                              (T*)ctx->ent_hid, (T*)ctx->ent_dpre, ctx->ent_off);
+    // + the transposition of g (left row-major by the decode launch) as a second kind of block in the same launch
+    const int ntr = (ldT / 64) * ceil_div(ctx->D, 64);
+    bucket_kernel<T><<<nchunks + ntr, 256, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, nt == 0 ? W2_M : TILE_M, ctx->ent_pos,
+                                                    (T*)ctx->ent_hid, (T*)ctx->ent_dpre, ctx->ent_off, nchunks, ctx->g,
+                                                    (T*)ctx->gT, ctx->D, ldT);
     WSAE_PROF_END(ctx, WSAE_K_BUCKET, st);
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD, st);
 #define WG_ARGS ctx->ent_pos, (const T*)ctx->ent_hid, (const T*)ctx->ent_dpre, ctx->ent_off, (const T*)ctx->xT, \
