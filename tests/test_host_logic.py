@@ -187,19 +187,28 @@ class TestTrainerHostLogic:
 
 class TestLazyMetrics:
     def test_fields_resolve_once_from_the_record(self):
-        rec = torch.zeros(N.STATS_WORDS, dtype=torch.int32)
-        rec.view(torch.float32)[:5] = torch.tensor([0.25, 8.0, 3.0, 0.5, 0.125])
+        from whisper_sae.sae.training import _MetricsRing
+        ring = _MetricsRing(chunk=2)
         calls = []
 
         class Stream:
             def synchronize(self):
                 calls.append(1)
 
-        m = _PendingMetrics(rec, Stream(), 1e-3, 5)
+        chunk, slot = ring.next("cpu")
+        chunk.dev[slot].view(torch.float32)[:5] = torch.tensor([0.25, 8.0, 3.0, 0.5, 0.125])
+        m = _PendingMetrics(chunk, slot, Stream(), 1e-3, 5)
+        chunk2, slot2 = ring.next("cpu")
+        assert chunk2 is chunk and slot2 == 1
+        chunk.dev[slot2].view(torch.float32)[:2] = torch.tensor([0.5, 4.0])
+        m2 = _PendingMetrics(chunk2, slot2, Stream(), 1e-3, 6)
         assert isinstance(m, TrainingMetrics) and m.step == 5 and m.learning_rate == 1e-3 and calls == []
         assert m.loss == 0.25 and calls == [1]
         assert (m.reconstruction_loss, m.sparsity_loss, m.l0, m.dead_feature_ratio) == (0.25, 0.0, 8.0, 0.125)
         assert (m.grad_norm, m.clip_coef) == (3.0, 0.5) and calls == [1]
+        assert (m2.loss, m2.l0) == (0.5, 4.0) and calls == [1]  # fetched together with the first record
+        chunk3, slot3 = ring.next("cpu")
+        assert chunk3 is not chunk and slot3 == 0  # a fresh zeroed chunk once the first is used up
         assert TrainingMetrics(0.5, 0.4, 0.1, 32.0, 0.1, 1e-4, 100).loss == 0.5
 
 

@@ -67,8 +67,12 @@ class FusedAdamW(Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, *, precision: int = N.PREC_FP32, max_norm: float = 0.0, grad_scale: float = 1.0,
-             normalize_decoder: bool = False, batch: int = 64, norm_from_wgrad: bool = False, dead_scan: bool = False):
-        """Apply one update from ``self.grads`` (filled by ``wsae_weight_grads``)."""
+             normalize_decoder: bool = False, batch: int = 64, norm_from_wgrad: bool = False, dead_scan: bool = False,
+             stats_ptr: int = 0):
+        """Apply one update from ``self.grads`` (filled by ``wsae_weight_grads``).
+
+        ``stats_ptr``: device address of the step record to fill (default: the engine's own record).
+        """
         if closure is not None:
             raise NotImplementedError("FusedAdamW does not take a closure")
         eng = self.module.bind()
@@ -84,7 +88,7 @@ class FusedAdamW(Optimizer):
                                         mod.feature_last_activated.data_ptr() if dead_scan else 0,
                                         mod.step_count.data_ptr() if dead_scan else 0,
                                         int(mod.dead_feature_threshold) if dead_scan else 0,
-                                        eng.stats.data_ptr(), eng.stream()), "wsae_adamw_step")
+                                        stats_ptr or eng.stats.data_ptr(), eng.stream()), "wsae_adamw_step")
         eng.mark_fresh(precision)
         for st in self.state.values():
             if "step" in st:

@@ -52,24 +52,25 @@ class TrainingMetrics:
 class _PendingMetrics(TrainingMetrics):
     """``TrainingMetrics`` whose device-produced fields are fetched on first access.
 
-    The values sit in a pinned host record that an async D2H copy fills; reading any of them
-    synchronises the producing stream once and then caches plain floats.
+    The kernels of a step write its record straight into a slot of a device-side record ring (no
+    per-step copy); reading any field synchronises the producing stream once, brings every finished
+    record of that ring chunk to the host in ONE copy, and then caches plain floats.
     """
 
     _LAZY = ("loss", "reconstruction_loss", "sparsity_loss", "l0", "dead_feature_ratio")
 
-    def __init__(self, record: Tensor, stream, learning_rate: float, step: int):  # noqa: D401 - no dataclass init
-        object.__setattr__(self, "_record", record)
+    def __init__(self, chunk: "_RecordChunk", slot: int, stream, learning_rate: float, step: int):  # noqa: D401
+        object.__setattr__(self, "_chunk", chunk)
+        object.__setattr__(self, "_slot", slot)
         object.__setattr__(self, "_stream", stream)
         object.__setattr__(self, "learning_rate", learning_rate)
         object.__setattr__(self, "step", step)
 
     def _resolve(self) -> None:
-        rec = self.__dict__.pop("_record", None)
-        if rec is None:
+        chunk = self.__dict__.pop("_chunk", None)
+        if chunk is None:
             return
-        self.__dict__.pop("_stream").synchronize()
-        f = rec.view(torch.float32)
+        f = chunk.host_record(self.__dict__.pop("_slot"), self.__dict__.pop("_stream"))
         self.__dict__.update(loss=float(f[0]), reconstruction_loss=float(f[0]), sparsity_loss=0.0, l0=float(f[1]),
                              dead_feature_ratio=float(f[4]), grad_norm=float(f[2]), clip_coef=float(f[3]))
 
@@ -80,21 +81,37 @@ class _PendingMetrics(TrainingMetrics):
         raise AttributeError(name)
 
 
+class _RecordChunk:
+    """``size`` zeroed step records on the device plus their lazily fetched host copy."""
+
+    def __init__(self, size: int, device):
+        self.dev = torch.zeros(size, N.STATS_WORDS, dtype=torch.int32, device=device)
+        self.used = 0          # slots handed out
+        self._host = None      # float32 view of the first _valid records
+        self._valid = 0
+
+    def host_record(self, slot: int, stream) -> Tensor:
+        if slot >= self._valid:
+            stream.synchronize()          # every record handed out so far is final after this
+            n = self.used
+            self._host = self.dev[:n].cpu().view(torch.float32)
+            self._valid = n
+        return self._host[slot]
+
+
 class _MetricsRing:
-    """Pinned host records for the async copies of the device step record."""
+    """Hands out one device record slot per step (a fresh zeroed chunk every ``chunk`` steps)."""
 
     def __init__(self, chunk: int = 4096):
         self.chunk = chunk
-        self.buf = None
-        self.used = 0
+        self.cur: Optional[_RecordChunk] = None
 
-    def next(self) -> Tensor:
-        if self.buf is None or self.used == self.chunk:
-            self.buf = torch.zeros(self.chunk, N.STATS_WORDS, dtype=torch.int32).pin_memory()
-            self.used = 0
-        rec = self.buf[self.used]
-        self.used += 1
-        return rec
+    def next(self, device) -> tuple:
+        if self.cur is None or self.cur.used == self.chunk:
+            self.cur = _RecordChunk(self.chunk, device)
+        slot = self.cur.used
+        self.cur.used += 1
+        return self.cur, slot
 
 
 class SAETrainer:
@@ -192,7 +209,8 @@ class SAETrainer:
         opt._ensure_state(eng)
         w = eng.work(B)
         pk, xd, rp = eng.pack.data_ptr(), _dtype_code(x), N.ptr(rows)
-        stats = eng.stats.data_ptr()
+        chunk, slot = self._records.next(eng.device)
+        stats = chunk.dev.data_ptr() + slot * N.STATS_WORDS * 4  # this step's record: written in place, never copied
         step_ptr = model.step_count.data_ptr()
         N.check(lib.wsae_encode_topk(handle, pk, x.data_ptr(), xd, rp, B, w["vals"].data_ptr(), w["idx"].data_ptr(),
                                      step_ptr, stats, st), "wsae_encode_topk")
@@ -205,14 +223,13 @@ class SAETrainer:
         # data parallel: mean of the per-rank mean-gradients + agreed dead-feature clock (RCCL all-reduces)
         grad_scale = sync_gradients(opt.grads, model.feature_last_activated)
         opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=grad_scale,
-                 normalize_decoder=True, batch=B, norm_from_wgrad=(grad_scale == 1.0), dead_scan=True)
+                 normalize_decoder=True, batch=B, norm_from_wgrad=(grad_scale == 1.0), dead_scan=True,
+                 stats_ptr=stats)
         self._token = model.param_token()
         if self.scheduler is not None:
             self.scheduler.step()
         self.global_step += 1
-        rec = self._records.next()
-        rec.copy_(eng.stats, non_blocking=True)
-        metrics = _PendingMetrics(rec, torch.cuda.current_stream(eng.device), opt.param_groups[0]["lr"],
+        metrics = _PendingMetrics(chunk, slot, torch.cuda.current_stream(eng.device), opt.param_groups[0]["lr"],
                                   self.global_step)
         if self.resample_dead:
             self._maybe_resample_dead_features()
