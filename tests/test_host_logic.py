@@ -233,17 +233,26 @@ class TestCacheFormat:
         class FakeRing:
             device = torch.device("cpu")
             data = torch.zeros(1000, 4)
+            launches = 0
 
             def __len__(self):
                 return 1000
 
+            def sample(self, n, seed, epoch, offset):  # identity "permutation": row index = position, tagged with the epoch
+                FakeRing.launches += 1
+                return torch.arange(offset, offset + n, dtype=torch.int32) + 10000 * epoch
+
             def batch(self, n, seed, epoch, offset):
-                return ("b", n, epoch, offset)
+                from whisper_sae.sae.training import RingBatch
+                return RingBatch(self.data, self.sample(n, seed, epoch, offset))
 
         ld = RingLoader(FakeRing(), 64)
         assert len(ld) == 16
         got = list(ld)
-        assert [g[1] for g in got] == [64] * 15 + [40] and [g[3] for g in got][:3] == [0, 64, 128]
-        assert [g[2] for g in list(ld)] == [1] * 16  # next epoch reshuffles
+        assert [len(g) for g in got] == [64] * 15 + [40]
+        assert [int(g.rows[0]) for g in got][:3] == [0, 64, 128] and int(got[-1].rows[-1]) == 999
+        assert torch.equal(torch.cat([g.rows for g in got]), torch.arange(1000, dtype=torch.int32))  # every row once
+        assert FakeRing.launches == 2  # 15 full steps in one launch + the ragged tail
+        assert [int(g.rows[0]) // 10000 for g in list(ld)] == [1] * 16  # next epoch reshuffles
         two = RingLoader(FakeRing(), 50, rank=1, world_size=2)
-        assert len(two) == 10 and [g[3] for g in two][:2] == [50, 150]
+        assert len(two) == 10 and [int(g.rows[0]) for g in two][:2] == [50, 150]

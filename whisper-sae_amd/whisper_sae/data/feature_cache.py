@@ -157,21 +157,41 @@ class RingLoader:
     def __len__(self) -> int:
         return math.ceil(len(self.ring) / (self.batch_size * self.world))
 
+    #: steps whose row indices are drawn by one ``wsae_ring_sample`` launch (a launch per step costs ~5 us
+    #: of a ~330 us step; the indices of 16 steps are 1 MB)
+    PREFETCH_STEPS = 16
+
     def __iter__(self) -> Iterator[RingBatch]:
         n = len(self.ring)
         per_step = self.batch_size * self.world
         epoch = self.epoch
         self.epoch += 1
-        for step in range(len(self)):
+        nsteps = len(self)
+        step = 0
+        while step < nsteps:
             lo = step * per_step + self.rank * self.batch_size
+            if not self.shuffle:
+                take = max(0, min(self.batch_size, n - lo))
+                if take == 0:
+                    lo, take = 0, min(self.batch_size, n)
+                rows = torch.arange(lo, lo + take, dtype=torch.int32, device=self.ring.device)
+                yield RingBatch(self.ring.data, rows)
+                step += 1
+                continue
+            # full global steps ahead of us: positions [step * per_step, (step + g) * per_step) of the epoch's permutation
+            g = min(self.PREFETCH_STEPS, nsteps - step, (n - step * per_step) // per_step)
+            if g >= 2:
+                block = self.ring.sample(g * per_step, self.seed, epoch, step * per_step).view(g, per_step)
+                mine = slice(self.rank * self.batch_size, (self.rank + 1) * self.batch_size)
+                for i in range(g):
+                    yield RingBatch(self.ring.data, block[i, mine])
+                step += g
+                continue
             take = max(0, min(self.batch_size, n - lo))
             if take == 0:  # ragged tail: this rank re-reads rows from the start of the permutation
                 lo, take = 0, min(self.batch_size, n)
-            if self.shuffle:
-                yield self.ring.batch(take, self.seed, epoch, lo)
-            else:
-                rows = torch.arange(lo, lo + take, dtype=torch.int32, device=self.ring.device)
-                yield RingBatch(self.ring.data, rows)
+            yield self.ring.batch(take, self.seed, epoch, lo)
+            step += 1
 
 
 class FeatureCache:
