@@ -481,6 +481,87 @@ encode_rows_kernel(const T* __restrict__ xb, const T* __restrict__ W, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// encode_gemm256p_kernel: the DENSE 256 x 256 GEMM as a persistent kernel - one workgroup per CU walks
+// tiles blockIdx.x, + gridDim.x, ...  What the walk buys over one workgroup per tile (768 tiles = three
+// rounds on 256 CUs, each paying its own start-up and drain): the first operand slabs of the NEXT tile are
+// requested before the epilogue of the current one, and the epilogue's 256 KB of stores drain
+// underneath the next tile's MFMAs instead of holding the CU until the workgroup retires.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(512)
+encode_gemm256p_kernel(const T* __restrict__ xb, const T* __restrict__ W, const float* __restrict__ bias,
+                       float* __restrict__ pre, int ldp, int B, int H, int D, int ntn, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = Mfma<T>::KT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves: 128-row halves x 64-column quarters
+    const int t2 = tid & 255, half = tid >> 8;  // each 256-thread half stages 128 rows of A and of W
+    const int nk = D / KT;
+    const int col = lane & 31, rq = lane >> 5;
+    constexpr int PS = 68;  // epilogue patch row stride in floats (see encode_gemm256_kernel)
+    float* patch = (float*)smem + wave * 32 * PS;
+    const int pr = lane >> 4, pc = (lane & 15) * 4;
+
+    SlabRegs<T> ra, rb;
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        slab_load_fast<T>(ra, xb, D, (tile / ntn) * 256 + 128 * half, B - 1, 0, t2);
+        slab_load_fast<T>(rb, W, D, (tile % ntn) * 256 + 128 * half, H - 1, 0, t2);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = (tile / ntn) * 256, n0 = (tile % ntn) * 256;
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            char* As = smem + (kt & 1) * 2 * T256_LDS;
+            char* Bs = As + T256_LDS;
+            slab_store<T>(ra, As + 128 * half * LDS_ROW_BYTES, t2);
+            slab_store<T>(rb, Bs + 128 * half * LDS_ROW_BYTES, t2);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                slab_load_fast<T>(ra, xb, D, m0 + 128 * half, B - 1, (kt + 1) * KT, t2);
+                slab_load_fast<T>(rb, W, D, n0 + 128 * half, H - 1, (kt + 1) * KT, t2);
+            }
+            Mfma256<T>::slab(As, Bs, wm * 128, wn * 64, lane, acc);
+        }
+        // next tile's first slabs fly during the epilogue (past the last tile: clamped re-read, unused)
+        {
+            const int nt = min(tile + (int)gridDim.x, ntiles - 1);
+            slab_load_fast<T>(ra, xb, D, (nt / ntn) * 256 + 128 * half, B - 1, 0, t2);
+            slab_load_fast<T>(rb, W, D, (nt % ntn) * 256 + 128 * half, H - 1, 0, t2);
+        }
+        __syncthreads();  // every wave is done reading the operand buffers: they become the transpose patches
+        const int hcol = n0 + wn * 64 + pc;
+        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hcol < H) bv4 = *(const float4*)(bias + hcol);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * rq) * PS + ni * 32 + col] = acc[mi][ni][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rl = pr + 4 * i;
+                const int b = m0 + wm * 128 + mi * 32 + rl;
+                float4 v = *(const float4*)(patch + rl * PS + pc);
+                v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+                if (b < B && hcol < H) *(float4*)(pre + (int64_t)b * ldp + hcol) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();  // patches read: the buffers may take the next tile's operands
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // TopK: one wave per row.
 //   key = (orderable(value) << 32) | ~index : descending key order == (value desc, index asc).
 //   1. per-lane maximum over the lane's share of the row;
@@ -846,9 +927,12 @@ static int gemm_dense(wsae_ctx* c, const float* params, int B, int nfeat, int ws
     dim3 gg(ceil_div(nfeat, TILE_N), ceil_div(B, TILE_M));
     WSAE_PROF_BEGIN(c, WSAE_K_ENCODE_GEMM, st);
     if (wstride == 1 && !arows && !n_dev && B >= 2048 && nfeat % 256 == 0 && c->D % Mfma<T>::KT == 0) {
-        dim3 g2(nfeat / 256, ceil_div(B, 256));
-        encode_gemm256_kernel<T, GEMM_DENSE><<<g2, 512, 4 * T256_LDS, st>>>(
-            (const T*)c->xb, W, bias, pre, ldp, B, nfeat, c->D, nullptr, 0, nullptr, nullptr, nullptr, 0);
+        const int ntn = nfeat / 256, ntiles = ntn * ceil_div(B, 256);
+        static int cus = 0;
+        if (!cus && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1))
+            cus = 256;
+        encode_gemm256p_kernel<T><<<min(ntiles, cus), 512, 4 * T256_LDS, st>>>((const T*)c->xb, W, bias, pre, ldp, B, nfeat,
+                                                                            c->D, ntn, ntiles);
     } else {
         encode_gemm_kernel<T, GEMM_DENSE><<<gg, 256, 2 * TILE_LDS_BYTES, st>>>(
             (const T*)c->xb, W, bias, pre, ldp, B, nfeat, c->D, wstride, arows, n_dev, nullptr, 0, nullptr, nullptr,
