@@ -97,6 +97,19 @@ int wsae_ctx_destroy(wsae_ctx* ctx);
  * filter cannot settle are recomputed exactly -- the [B,H] matrix never reaches HBM.  Same results either
  * way; on MI355X at 384->3072/B=16384 the dense path is currently the faster one. */
 int wsae_ctx_set_fused_topk(wsae_ctx* ctx, int32_t on);
+
+/* Data-parallel dead-feature clock without a second collective.  `fired` = float[hidden_dim], zero
+ * before the first step, or NULL to switch the mechanism off (the default).  When set:
+ *   - wsae_decode_loss stores 1.0f to fired[f] for every feature f it stamps in last_activated
+ *     (model.py:178-181);
+ *   - the caller sums `fired` over the ranks (it rides at the tail of the gradient all-reduce);
+ *   - wsae_adamw_step then sets last_activated[f] = *step_count wherever fired[f] > 0 and clears
+ *     fired for the next step.
+ * With clocks that agreed before the step this equals all_reduce(MAX) of last_activated: a feature
+ * either fired somewhere in this step (new value = the step) or nowhere (value unchanged, equal on
+ * every rank).  Replaces the 8*H-byte MAX all-reduce the reference's semantics would otherwise need
+ * under DDP (the reference itself is single-process). */
+int wsae_ctx_set_fired(wsae_ctx* ctx, float* fired);
 size_t wsae_ctx_workspace_bytes(const wsae_ctx* ctx);
 
 /* Refresh what the kernels derive from the master weights: bf16 shadow of W_e and the folded
@@ -169,7 +182,7 @@ int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads, float* exp
                     float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step, float max_norm, float grad_scale,
                     int32_t normalize_decoder, int32_t norm_from_wgrad,
-                    const int64_t* last_activated, const int64_t* step_count,
+                    int64_t* last_activated, const int64_t* step_count,
                     int64_t dead_threshold, wsae_stats* stats, void* stream);
 
 /* F.normalize(decoder.weight, dim=0) alone (model.py:91-96) + shadow refresh. */

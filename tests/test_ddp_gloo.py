@@ -2,9 +2,11 @@
 
 Each rank computes the oracle's gradients on its own half batch, packs them in the flat layout the
 kernels use, and calls ``whisper_sae.distributed.sync_gradients`` (the function the trainer calls
-between ``wsae_weight_grads`` and ``wsae_adamw_step``).  The result, scaled by the returned factor,
-must equal the oracle's gradients on the concatenated batch, and the merged dead-feature clocks must
-equal the single-process clocks -- i.e. DDP over N ranks is the single-device step on N*B rows.
+between ``wsae_weight_grads`` and ``wsae_adamw_step``) on the buffer ``[gradients | fired]``.  The
+result, scaled by the returned factor, must equal the oracle's gradients on the concatenated batch, and
+the dead-feature clocks merged from the summed ``fired`` indicators (what ``wsae_adamw_step`` does on
+the device, restated by ``merge_clock``) must equal the single-process clocks -- i.e. DDP over N ranks
+is the single-device step on N*B rows, with ONE collective.
 """
 
 from __future__ import annotations
@@ -21,7 +23,7 @@ import torch.multiprocessing as mp
 from oracle import sae_oracle as O
 from oracle import synth
 from whisper_sae import _native as N
-from whisper_sae.distributed import rank_and_world, sync_gradients
+from whisper_sae.distributed import merge_clock, rank_and_world, sync_gradients
 
 D, H, K, B = 64, 256, 8, 32
 PACK_ORDER = ("W_e", "W_d", "b_e", "b_d", "b_pre")
@@ -45,13 +47,20 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
         assert rank_and_world() == (rank, world)
         w = synth.sae_weights(D, H, seed=3, bf16=False, b_pre_scale=0.05)
         st = O.SAEState.from_state_dict(w, k=K, dead_feature_threshold=5)
+        clocks_before = st.last_activated.copy()
         x = synth.activations(world * B, D, seed=3, stream=8, bf16=False)
         mine = x[rank * B:(rank + 1) * B]
         fwd = O.forward(st, mine, "fp32", training=True)
-        flat = pack(O.backward(st, mine, fwd, "fp32"))
-        last = torch.from_numpy(st.last_activated.copy())
-        scale = sync_gradients(flat, last)
+        grads = pack(O.backward(st, mine, fwd, "fp32"))
+        step = int(st.step_count)
+        local = torch.from_numpy(st.last_activated.copy())
+        fired = (local == step).to(torch.float32)  # what the decode kernel stores: 1.0 where this rank stamped the clock
+        last = torch.from_numpy(clocks_before.copy())  # every rank starts the step with the agreed clocks
+        flat = torch.cat([grads, fired])
+        scale = sync_gradients(flat)
         assert scale == 1.0 / world
+        last = merge_clock(last, flat[grads.numel():], step)
+        flat = flat[:grads.numel()]
         np.save(os.path.join(out_dir, f"g{rank}.npy"), (flat * scale).numpy())
         np.save(os.path.join(out_dir, f"l{rank}.npy"), last.numpy())
     finally:
@@ -82,5 +91,7 @@ def test_two_rank_gradient_average_equals_full_batch(tmp_path):
 
 def test_single_process_is_a_no_op():
     flat = torch.arange(8, dtype=torch.float32)
-    assert sync_gradients(flat, None) == 1.0 and torch.equal(flat, torch.arange(8, dtype=torch.float32))
+    assert sync_gradients(flat) == 1.0 and torch.equal(flat, torch.arange(8, dtype=torch.float32))
+    last = torch.tensor([3, 0, 7], dtype=torch.int64)
+    assert merge_clock(last, torch.tensor([0.0, 2.0, 0.0]), 9).tolist() == [3, 9, 7]
     assert rank_and_world() == (0, 1)

@@ -260,6 +260,46 @@ class TestDeadFeatures:
         assert np.array_equal(sd["encoder.bias"] == 0, g[f"{tag}.b_e"] == 0)
 
 
+class TestDdpClock:
+    """The one-collective dead-feature clock (include/wsae.h, wsae_ctx_set_fired) on a single GPU: the trainer
+    is told it runs data-parallel and the 'all-reduce' is replaced by a function that adds what a second
+    rank would have contributed to the fired indicators."""
+
+    def test_fired_indicators_merge_like_all_reduce_max(self, device, tmp_path, monkeypatch):
+        from whisper_sae.config import TrainingConfig
+        from whisper_sae.sae import training as T
+        D, H, K, B = 64, 256, 8, 32
+        m, st = build(D, H, K, 3, False, 0.05, 5, device, "fp32")
+        cfg = TrainingConfig(batch_size=B, learning_rate=1e-3, weight_decay=0.0, epochs=1, warmup_steps=0,
+                             gradient_clip=1.0, use_amp=False, num_workers=0)
+        tr = T.SAETrainer(m, cfg, device=device, run_dir=tmp_path)
+        x_all = synth.activations(2 * B, D, seed=3, stream=8, bf16=False)
+        mine, theirs = x_all[:B], x_all[B:]
+        # what the other rank's decode launch would have stamped in this step
+        other = O.forward(st, theirs, "fp32", training=False)
+        fired_other = torch.from_numpy(((other["hidden"] > 0).any(axis=0)).astype(np.float32)).to(device)
+        seen = {}
+
+        def fake_all_reduce(flat):
+            P = flat.numel() - H
+            seen["local"] = flat[P:].clone()
+            flat[P:] += fired_other     # SUM over the two ranks
+            flat[:P] *= 2.0             # (both ranks hold this rank's gradients: sum = 2x, scale 1/2 below)
+            return 0.5
+
+        monkeypatch.setattr(T, "world", lambda: (None, 2))
+        monkeypatch.setattr(T, "sync_gradients", fake_all_reduce)
+        tr.train_step(torch.from_numpy(mine).to(device))
+        torch.cuda.synchronize()
+        fwd = O.forward(st, mine, "fp32", training=True)      # this rank's own stamps (step_count -> 1)
+        local = (fwd["hidden"] > 0).any(axis=0)
+        assert np.array_equal(seen["local"].cpu().numpy() > 0, local)  # decode wrote exactly its own features
+        want = np.where(local | (fired_other.cpu().numpy() > 0), 1, 0).astype(np.int64)  # all_reduce(MAX) of the clocks
+        assert np.array_equal(m.feature_last_activated.cpu().numpy(), want)
+        assert float(tr.optimizer.fired.abs().sum().item()) == 0.0  # cleared for the next step
+        assert int(m.step_count.item()) == 1
+
+
 class TestTopKKernel:
     """The TopK kernel against the oracle's selection rule, including its exact (bisection) path."""
 

@@ -101,6 +101,7 @@ struct wsae_ctx {
     int32_t* cand_cnt;    // [maxB][ceil(H/128)]
     int32_t* cand_ovf;    // [maxB] slot-group overflow flags
     int32_t* flag_rows;   // [maxB] rows sent to the exact fallback
+    float* fired;         // caller-owned [H] indicator buffer for the DDP dead-feature clock, or null
     int fused_topk;       // 1: filter path (sample threshold + filtering GEMM) instead of dense GEMM + TopK
     int n_dec_blocks;     // blocks used by the last decode launch (partials to reduce)
     int n_sq_parts;       // global-norm partials left in part_sq by the last wsae_weight_grads

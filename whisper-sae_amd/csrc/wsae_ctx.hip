@@ -221,6 +221,12 @@ extern "C" int wsae_profile_read(wsae_ctx* ctx, int32_t kernel_id, int32_t* n_la
     return WSAE_OK;
 }
 
+extern "C" int wsae_ctx_set_fired(wsae_ctx* ctx, float* fired) {
+    WSAE_REQUIRE(ctx, "wsae_ctx_set_fired: null ctx");
+    ctx->fired = fired;
+    return WSAE_OK;
+}
+
 extern "C" int wsae_ctx_set_fused_topk(wsae_ctx* ctx, int32_t on) {
     WSAE_REQUIRE(ctx, "wsae_ctx_set_fused_topk: null ctx");
     ctx->fused_topk = on ? 1 : 0;

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256)
 decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const float* __restrict__ bpre,
               const void* __restrict__ x, const int32_t* __restrict__ rows, const float* __restrict__ vals,
               const int32_t* __restrict__ idx, int B, int D, int K, float* __restrict__ recon_out,
-              float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated,
+              float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated, float* __restrict__ fired,
               const int64_t* __restrict__ step_count, float* __restrict__ part_loss, float* __restrict__ part_l0,
               float* __restrict__ part_dbd, int32_t* __restrict__ ticket, wsae_stats* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -86,7 +86,10 @@ decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const fl
             const int f = (lane < nj) ? idx[code + jb + lane] : 0;
             const bool on = v > 0.f;
             l0_acc += __popcll(__ballot(on));
-            if (on && last_activated) last_activated[f] = step;  // model.py:178-181 (same value from every writer)
+            if (on && last_activated) {
+                last_activated[f] = step;  // model.py:178-181 (same value from every writer)
+                if (fired) fired[f] = 1.f;
+            }
             for (int j = 0; j < nj; ++j) {
                 const float vj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j));
                 if (!(vj > 0.f)) continue;
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(256, 2)
 decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const float* __restrict__ bpre,
                    const void* __restrict__ x, const int32_t* __restrict__ rows, const float* __restrict__ vals,
                    const int32_t* __restrict__ idx, int B, int K, float* __restrict__ recon_out,
-                   float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated,
+                   float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated, float* __restrict__ fired,
                    const int64_t* __restrict__ step_count, float* __restrict__ part_loss,
                    float* __restrict__ part_l0, float* __restrict__ part_dbd, int32_t* __restrict__ ticket,
                    wsae_stats* __restrict__ stats) {
@@ -286,7 +289,10 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
         const int f_l = f_n;
         const bool on = v_l > 0.f;
         l0_acc += __popcll(__ballot(on));
-        if (on && last_activated) last_activated[f_l] = step;  // model.py:178-181
+        if (on && last_activated) {
+            last_activated[f_l] = step;  // model.py:178-181
+            if (fired) fired[f_l] = 1.f;
+        }
         const float vr_l = on ? v_l : 0.f;
 
         Seg seg[KJ];
@@ -424,7 +430,7 @@ static void launch_decode(wsae_ctx* c, const TW* WdT, const float* params, const
     const float* bd = params + c->off[3];
     const float* bpre = params + c->off[4];
     const size_t sh = (8 + 4 * (size_t)c->D) * sizeof(float);
-#define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->D, c->K, recon, dpre, c->g, last_activated, step_count, \
+#define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->D, c->K, recon, dpre, c->g, last_activated, c->fired, step_count, \
                  c->part_loss, c->part_l0, c->part_dbd, c->counters + 16 + 2 * TICKET_WORDS, stats
     if (!want_bwd)
         decode_kernel<TW, EPL, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
@@ -442,7 +448,7 @@ static void launch_decode_fast(wsae_ctx* c, const TW* WdT, const float* params, 
     const float* bd = params + c->off[3];
     const float* bpre = params + c->off[4];
     const size_t sh = (8 + 5 * (size_t)c->D) * sizeof(float);
-#define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->K, recon, dpre, c->g, last_activated, step_count, \
+#define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->K, recon, dpre, c->g, last_activated, c->fired, step_count, \
                  c->part_loss, c->part_l0, c->part_dbd, c->counters + 16 + 2 * TICKET_WORDS, stats
     if (!want_bwd)
         decode_fast_kernel<TW, EPL, KJ, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);

@@ -236,9 +236,9 @@ __global__ void __launch_bounds__(256)
 update_rows_kernel(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M, float* __restrict__ V,
                    int64_t oWe, int64_t oWd, int64_t oBe, int64_t oBd, int64_t oBp, int H, int D,
                    const float* __restrict__ part_sq, int nparts, AdamArgs a, bf16_t* __restrict__ We16,
-                   bf16_t* __restrict__ WdT16, float* __restrict__ cfold, const int64_t* __restrict__ last,
+                   bf16_t* __restrict__ WdT16, float* __restrict__ cfold, int64_t* __restrict__ last,
                    const int64_t* __restrict__ step_count, int64_t thr, int32_t* __restrict__ counters,
-                   wsae_stats* __restrict__ stats) {
+                   wsae_stats* __restrict__ stats, float* __restrict__ fired) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bp_s = (float*)smem;  // [D] updated b_pre
     __shared__ float red[8];
@@ -256,9 +256,11 @@ update_rows_kernel(float* __restrict__ P, const float* __restrict__ G, float* __
     if (BOTH) row_load<NI>(rd, P, G, M, V, oWd + (int64_t)hc * D, D, lane);
     float be_p = P[oBe + hc], be_g = G[oBe + hc], be_m = M[oBe + hc], be_v = V[oBe + hc];
     int64_t la = 0, sc = 0;
+    float fr = 0.f;
     if (last) {
         la = last[hc];
         sc = *step_count;
+        if (fired) fr = fired[hc];  // summed over the ranks: > 0 when the feature fired anywhere in this step
     }
 
     // ---- per-block prologue: clip coefficient, the NEW b_pre (every block computes it from the old
@@ -344,7 +346,14 @@ update_rows_kernel(float* __restrict__ P, const float* __restrict__ G, float* __
                 }
             }
         }
-        if (last) dead = ((sc - la) > thr) ? 1 : 0;
+        if (last) {
+            if (fired && lane == 0) {  // DDP clock merge (include/wsae.h, wsae_ctx_set_fired)
+                if (fr > 0.f) last[h] = sc;
+                fired[h] = 0.f;
+            }
+            if (fr > 0.f) la = sc;
+            dead = ((sc - la) > thr) ? 1 : 0;
+        }
     }
     // arrival ticket (low word also sums the dead-feature count); every block's reads of the old
     // b_pre / b_d state precede its ticket, so the last arriver may overwrite that state
@@ -372,10 +381,10 @@ update_rows_kernel(float* __restrict__ P, const float* __restrict__ G, float* __
 
 template <int NI>
 static void launch_update_rows(bool normalize, bool shadow, int nb, size_t sh, hipStream_t st, float* P, const float* G,
-                               float* M, float* V, wsae_ctx* ctx, int nparts, const AdamArgs& a, const int64_t* last,
+                               float* M, float* V, wsae_ctx* ctx, int nparts, const AdamArgs& a, int64_t* last,
                                const int64_t* step_count, int64_t thr, wsae_stats* stats) {
 #define UP_ARGS P, G, M, V, ctx->off[0], ctx->off[1], ctx->off[2], ctx->off[3], ctx->off[4], ctx->H, ctx->D, ctx->part_sq, \
-                nparts, a, ctx->We_bf16, ctx->WdT_bf16, ctx->c_fold, last, step_count, thr, ctx->counters, stats
+                nparts, a, ctx->We_bf16, ctx->WdT_bf16, ctx->c_fold, last, step_count, thr, ctx->counters, stats, ctx->fired
     if (normalize && shadow) update_rows_kernel<true, true, NI><<<nb, 256, sh, st>>>(UP_ARGS);
     else if (normalize) update_rows_kernel<true, false, NI><<<nb, 256, sh, st>>>(UP_ARGS);
     else if (shadow) update_rows_kernel<false, true, NI><<<nb, 256, sh, st>>>(UP_ARGS);
@@ -391,7 +400,7 @@ extern "C" int wsae_normalize_decoder(wsae_ctx* ctx, float* params, void* stream
 extern "C" int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                                float max_norm, float grad_scale, int32_t normalize_decoder, int32_t norm_from_wgrad,
-                               const int64_t* last_activated, const int64_t* step_count, int64_t dead_threshold,
+                               int64_t* last_activated, const int64_t* step_count, int64_t dead_threshold,
                                wsae_stats* stats, void* stream) {
     WSAE_REQUIRE(ctx && params && grads && exp_avg && exp_avg_sq, "wsae_adamw_step: null argument");
     WSAE_REQUIRE(step >= 1, "wsae_adamw_step: step is the 1-based update count, got %d", step);

@@ -6,10 +6,12 @@ average over their own B rows and then average the gradients reproduce exactly t
 concatenated N*B batch.  One process per GPU; ``torch.distributed`` backend ``"nccl"`` is RCCL on
 ROCm (xGMI inside a node); ``"gloo"`` runs the same code on CPU tensors for tests.
 
-Per step there is ONE collective on the critical path -- ``all_reduce(SUM)`` of the flat gradient
-pack (9.45 MB fp32 at 384->3072; the 1/world factor is folded into the fused optimizer kernel as
-``grad_scale``) -- plus a 24 KB ``all_reduce(MAX)`` of ``feature_last_activated`` so every rank
-holds the same dead-feature clock and therefore the same dead mask.
+Per step there is ONE collective: ``all_reduce(SUM)`` of the flat buffer ``[gradient pack | fired]``
+(9.45 MB + 12 KB fp32 at 384->3072; the 1/world factor is folded into the fused optimizer kernel as
+``grad_scale``).  ``fired[f]`` is 1.0 on the ranks where feature f fired in this step; its sum tells
+every rank which ``feature_last_activated`` entries to stamp with the current step, which equals an
+``all_reduce(MAX)`` of the clocks (clocks that agreed before the step either all advance to the step or
+all stay) without a second, latency-bound collective.
 """
 
 from __future__ import annotations
@@ -25,18 +27,22 @@ def world():
     return None, 1
 
 
-def sync_gradients(flat_grads: torch.Tensor, last_activated: torch.Tensor | None = None) -> float:
-    """Sum the gradient pack over all ranks (in place) and merge the dead-feature clocks.
+def sync_gradients(flat: torch.Tensor) -> float:
+    """Sum ``flat`` (gradient pack, optionally followed by the fired indicators) over all ranks, in place.
 
     Returns the factor the caller must scale the summed gradients by (``1 / world_size``).
     """
     dist, n = world()
     if dist is None:
         return 1.0
-    dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
-    if last_activated is not None:
-        dist.all_reduce(last_activated, op=dist.ReduceOp.MAX)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return 1.0 / n
+
+
+def merge_clock(last_activated: torch.Tensor, fired_sum: torch.Tensor, step: int) -> torch.Tensor:
+    """What ``wsae_adamw_step`` does with the summed indicators (host restatement for tests and CPU tools):
+    ``last_activated[f] = step`` wherever any rank fired f in this step."""
+    return torch.where(fired_sum > 0, torch.full_like(last_activated, step), last_activated)
 
 
 def rank_and_world() -> tuple:

@@ -37,7 +37,11 @@ class FusedAdamW(Optimizer):
             return
         self._m = torch.zeros(eng.P, dtype=torch.float32, device=eng.device)
         self._v = torch.zeros(eng.P, dtype=torch.float32, device=eng.device)
-        self.grads = torch.zeros(eng.P, dtype=torch.float32, device=eng.device)
+        # [gradient pack (P) | fired indicators (H)]: under DDP the whole buffer is ONE all-reduce, the tail
+        # carrying the dead-feature clock merge (include/wsae.h, wsae_ctx_set_fired)
+        self.grads_ext = torch.zeros(eng.P + eng.H, dtype=torch.float32, device=eng.device)
+        self.grads = self.grads_ext[:eng.P]
+        self.fired = self.grads_ext[eng.P:]
         self._alias_state(eng)
 
     def _alias_state(self, eng) -> None:

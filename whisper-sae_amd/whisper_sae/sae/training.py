@@ -31,7 +31,7 @@ from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
 
 from .. import _native as N
 from ..config import TrainingConfig
-from ..distributed import sync_gradients
+from ..distributed import sync_gradients, world
 from .engine import _dtype_code, require_device_tensor
 from .optim import FusedAdamW
 
@@ -212,6 +212,8 @@ class SAETrainer:
         chunk, slot = self._records.next(eng.device)
         stats = chunk.dev.data_ptr() + slot * N.STATS_WORDS * 4  # this step's record: written in place, never copied
         step_ptr = model.step_count.data_ptr()
+        ddp = world()[1] > 1
+        N.check(lib.wsae_ctx_set_fired(handle, opt.fired.data_ptr() if ddp else 0), "wsae_ctx_set_fired")
         N.check(lib.wsae_encode_topk(handle, pk, x.data_ptr(), xd, rp, B, w["vals"].data_ptr(), w["idx"].data_ptr(),
                                      step_ptr, stats, st), "wsae_encode_topk")
         N.check(lib.wsae_decode_loss(handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(), B, 0,
@@ -220,8 +222,9 @@ class SAETrainer:
         N.check(lib.wsae_weight_grads(handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(),
                                       w["dpre"].data_ptr(), B, opt.grads.data_ptr(), st), "wsae_weight_grads")
         eng.generation += 1
-        # data parallel: mean of the per-rank mean-gradients + agreed dead-feature clock (RCCL all-reduces)
-        grad_scale = sync_gradients(opt.grads, model.feature_last_activated)
+        # data parallel: ONE RCCL all-reduce of [gradients | fired indicators]; the optimizer kernel applies
+        # 1/world and stamps the dead-feature clock of every feature that fired on any rank
+        grad_scale = sync_gradients(opt.grads_ext) if ddp else 1.0
         opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=grad_scale,
                  normalize_decoder=True, batch=B, norm_from_wgrad=(grad_scale == 1.0), dead_scan=True,
                  stats_ptr=stats)
