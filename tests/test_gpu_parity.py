@@ -260,6 +260,27 @@ class TestDeadFeatures:
         assert np.array_equal(sd["encoder.bias"] == 0, g[f"{tag}.b_e"] == 0)
 
 
+class TestDeterminism:
+    def test_two_runs_of_three_steps_are_bit_identical(self, device, tmp_path):
+        """No float atomics on the step path: every cross-block sum has a fixed order, so the same inputs
+        give the same bits (bf16 mode, cfg-2 dimensions)."""
+        from whisper_sae.config import TrainingConfig
+        from whisper_sae.sae.training import SAETrainer
+        D, H, K, B = 384, 3072, 32, 1024
+        packs = []
+        for run in range(2):
+            m, _ = build(D, H, K, 11, True, 0.05, 1000, device, "bf16")
+            cfg = TrainingConfig(batch_size=B, learning_rate=1e-3, weight_decay=0.0, epochs=1, warmup_steps=0,
+                                 gradient_clip=1.0, use_amp=True, num_workers=0)
+            tr = SAETrainer(m, cfg, device=device, run_dir=tmp_path / f"r{run}")
+            for step in range(3):
+                x = torch.from_numpy(synth.activations(B, D, seed=11, stream=20 + step, bf16=True)).to(device)
+                tr.train_step(x)
+            torch.cuda.synchronize()
+            packs.append(m._engine.pack.clone())
+        assert torch.equal(packs[0], packs[1])
+
+
 class TestDdpClock:
     """The one-collective dead-feature clock (include/wsae.h, wsae_ctx_set_fired) on a single GPU: the trainer
     is told it runs data-parallel and the 'all-reduce' is replaced by a function that adds what a second
