@@ -156,10 +156,13 @@ def main() -> None:
         roof = None
         if n_w:
             flops_per_launch = 2 * (2.0 * HIDDEN * D_MODEL * B)
+            # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
+            # (r01_v3_pmc_traffic.csv: 2 x FETCH_SIZE + WRITE_SIZE); measured at the default configuration only
+            traffic = 100.7e6 if (B == 16384 and args.precision == "bf16") else None
             achieved = flops_per_launch / (ms_w / n_w * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "wgrad_kernel<bf16>", "achieved": achieved,
                     "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
-                    "traffic": None, "avg_launch_ms": ms_w / n_w, "launches": n_w,
+                    "traffic": traffic, "avg_launch_ms": ms_w / n_w, "launches": n_w,
                     "step_dense_equiv_tflops": value * f_dense / 1e12,
                     "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS}
         out = {

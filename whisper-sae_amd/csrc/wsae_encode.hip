@@ -502,13 +502,27 @@ encode_gemm256p_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
     float* patch = (float*)smem + wave * 32 * PS;
     const int pr = lane >> 4, pc = (lane & 15) * 4;
 
+    // XCD-aware walk: workgroup w runs on XCD w % 8.  When the batch tiles divide evenly over the XCDs
+    // every XCD gets whole batch tiles (all ntn feature tiles of each), so its L2 reads a batch tile once
+    // instead of once per feature tile on every XCD (111 MB -> the 15 MB of operands; profiles/README.md).
+    // Walk index i (this workgroup's i-th tile) -> global tile id:
+    const int ntm = ntiles / ntn;
+    const bool xcd_walk = (gridDim.x % 8 == 0) && (ntm % 8 == 0);
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    auto tile_at = [&](int i) -> int {
+        if (!xcd_walk) return (int)blockIdx.x + i * (int)gridDim.x;
+        const int tl = local + i * per_xcd;                 // index among this XCD's (ntm / 8) * ntn tiles
+        if (tl >= (ntm >> 3) * ntn) return ntiles;          // past the end
+        return (xcd * (ntm >> 3) + tl / ntn) * ntn + tl % ntn;
+    };
     SlabRegs<T> ra, rb;
-    int tile = blockIdx.x;
+    int it = 0;
+    int tile = tile_at(0);
     if (tile < ntiles) {
         slab_load_fast<T>(ra, xb, D, (tile / ntn) * 256 + 128 * half, B - 1, 0, t2);
         slab_load_fast<T>(rb, W, D, (tile % ntn) * 256 + 128 * half, H - 1, 0, t2);
     }
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < ntiles; tile = tile_at(++it)) {
         const int m0 = (tile / ntn) * 256, n0 = (tile % ntn) * 256;
         f32x16 acc[4][2];
 #pragma unroll
@@ -531,7 +545,7 @@ encode_gemm256p_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
         }
         // next tile's first slabs fly during the epilogue (past the last tile: clamped re-read, unused)
         {
-            const int nt = min(tile + (int)gridDim.x, ntiles - 1);
+            const int nt = min(tile_at(it + 1), ntiles - 1);
             slab_load_fast<T>(ra, xb, D, (nt / ntn) * 256 + 128 * half, B - 1, 0, t2);
             slab_load_fast<T>(rb, W, D, (nt % ntn) * 256 + 128 * half, H - 1, 0, t2);
         }
