@@ -260,6 +260,89 @@ class TestDeadFeatures:
         assert np.array_equal(sd["encoder.bias"] == 0, g[f"{tag}.b_e"] == 0)
 
 
+class TestReLUSAE:
+    """ReLU + L1 SAE (reference model.py:260-322) through wsae_relu_forward/backward."""
+
+    def _build(self, D, H, seed, bf16, device, precision, weight=0.01):
+        from whisper_sae.sae.model import ReLUSAE
+        w = synth.sae_weights(D, H, seed=seed, bf16=bf16)
+        m = ReLUSAE(D, H, sparsity_weight=weight, precision=precision)
+        sd = m.state_dict()
+        for key in ("encoder.weight", "encoder.bias", "decoder.weight", "decoder.bias"):
+            sd[key] = torch.from_numpy(w[key])
+        m.load_state_dict(sd)
+        return m.to(device), w
+
+    def test_g8_forward_backward_fp32(self, golden_dir, device):
+        g = np.load(golden_dir / "g8_relu.npz")
+        D, H, B = (int(v) for v in g["dims"])
+        m, _ = self._build(D, H, 11, False, device, "fp32")
+        x = synth.activations(B, D, seed=11, stream=5, bf16=False)
+        out = m(torch.from_numpy(x).to(device))
+        out.loss.backward()
+        assert abs(float(out.loss.detach()) - float(g["loss"])) / float(g["loss"]) < 1e-5
+        assert abs(float(out.reconstruction_loss) - float(g["mse"])) / float(g["mse"]) < 1e-5
+        assert abs(float(out.sparsity_loss) - float(g["l1"])) / float(g["l1"]) < 1e-5
+        assert float(out.l0) == float(g["l0"])
+        assert int((out.hidden > 0).sum().item()) == int(g["hidden_nnz"])
+        assert rel(cpu(out.reconstructed), g["recon"]) < 1e-5
+        for p, key in ((m.encoder.weight, "dW_e"), (m.encoder.bias, "db_e"), (m.decoder.weight, "dW_d"),
+                       (m.decoder.bias, "db_d")):
+            assert rel(cpu(p.grad), g[key]) < 2e-5, key
+
+    @pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+    def test_ragged_shapes_against_the_oracle(self, device, precision, tol):
+        """Batch and widths that are not multiples of the 64/128 tiles (B = 200, D = 96, H = 352)."""
+        D, H, B = 96, 352, 200
+        m, w = self._build(D, H, 5, True, device, precision, weight=0.05)
+        x = synth.activations(B, D, seed=5, stream=2, bf16=True)
+        out = m(torch.from_numpy(x).to(device))
+        out.loss.backward()
+        args = (w["encoder.weight"], w["encoder.bias"], w["decoder.weight"], w["decoder.bias"], x)
+        f = O.relu_forward(*args, sparsity_weight=0.05)
+        b = O.relu_backward(*args, f, sparsity_weight=0.05)
+        ftol = 1e-5 if precision == "fp32" else 5e-3
+        assert abs(float(out.loss.detach()) - float(f["loss"])) / float(f["loss"]) < ftol
+        assert abs(float(out.sparsity_loss) - float(f["sparsity_loss"])) / float(f["sparsity_loss"]) < ftol
+        assert rel(cpu(out.reconstructed), f["reconstructed"]) < ftol
+        for p, key in ((m.encoder.weight, "W_e"), (m.encoder.bias, "b_e"), (m.decoder.weight, "W_d"),
+                       (m.decoder.bias, "b_d")):
+            assert rel(cpu(p.grad), b[key]) < tol, key
+
+    def test_trainer_step_matches_autograd_plus_adamw(self, device, tmp_path):
+        """SAETrainer drives the ReLU module (the reference's trainer crashes on it): one fused step equals the
+        oracle's gradients -> clip -> AdamW -> decoder renorm on the same weights."""
+        from whisper_sae.config import TrainingConfig
+        from whisper_sae.sae.training import SAETrainer
+        D, H, B = 64, 256, 32
+        m, w = self._build(D, H, 11, False, device, "fp32")
+        cfg = TrainingConfig(batch_size=B, learning_rate=1e-3, weight_decay=0.0, epochs=1, warmup_steps=0,
+                             gradient_clip=1.0, use_amp=False, num_workers=0)
+        tr = SAETrainer(m, cfg, device=device, run_dir=tmp_path)
+        x = synth.activations(B, D, seed=11, stream=5, bf16=False)
+        met = tr.train_step(torch.from_numpy(x).to(device))
+        args = (w["encoder.weight"], w["encoder.bias"], w["decoder.weight"], w["decoder.bias"], x)
+        f = O.relu_forward(*args, sparsity_weight=0.01)
+        gr = O.relu_backward(*args, f, sparsity_weight=0.01)
+        assert abs(met.loss - float(f["loss"])) / float(f["loss"]) < 1e-5
+        assert abs(met.sparsity_loss - float(f["sparsity_loss"])) / float(f["sparsity_loss"]) < 1e-5
+        assert abs(met.reconstruction_loss - float(f["reconstruction_loss"])) / float(f["reconstruction_loss"]) < 1e-4
+        names = {"W_e": "encoder.weight", "b_e": "encoder.bias", "W_d": "decoder.weight", "b_d": "decoder.bias"}
+        norm = np.sqrt(sum(float((gr[k].astype(np.float64) ** 2).sum()) for k in names))
+        coef = min(1.0, 1.0 / (norm + 1e-6))
+        sd = {k: cpu(v) for k, v in m.state_dict().items()}
+        for k, name in names.items():
+            gc = gr[k].astype(np.float64) * coef
+            m1 = 0.1 * gc
+            v1 = 0.001 * gc * gc
+            upd = (m1 / 0.1) / (np.sqrt(v1 / 0.001) + 1e-8)
+            want = w[name].astype(np.float64) - 1e-3 * upd
+            if k == "W_d":
+                want = want / np.maximum(np.linalg.norm(want, axis=0, keepdims=True), 1e-12)
+            assert np.abs(sd[name] - want).max() < 2e-6, name
+        assert float(m._engine.view("b_pre").abs().max().item()) == 0.0  # the unused pre-bias slot stays exactly zero
+
+
 class TestDeterminism:
     def test_two_runs_of_three_steps_are_bit_identical(self, device, tmp_path):
         """No float atomics on the step path: every cross-block sum has a fixed order, so the same inputs

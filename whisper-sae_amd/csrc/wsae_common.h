@@ -101,6 +101,7 @@ struct wsae_ctx {
     int32_t* cand_cnt;    // [maxB][ceil(H/128)]
     int32_t* cand_ovf;    // [maxB] slot-group overflow flags
     int32_t* flag_rows;   // [maxB] rows sent to the exact fallback
+    void* relu_ws;        // ReLU-SAE workspace (wsae_relu.hip), allocated by the first wsae_relu_forward
     float* fired;         // caller-owned [H] indicator buffer for the DDP dead-feature clock, or null
     int fused_topk;       // 1: filter path (sample threshold + filtering GEMM) instead of dense GEMM + TopK
     int n_dec_blocks;     // blocks used by the last decode launch (partials to reduce)
@@ -192,3 +193,7 @@ __device__ __forceinline__ float load_act(const void* p, int64_t i) {
 }
 
 #endif  // __HIPCC__
+
+// internal (wsae_encode.hip): stage the batch (xb, xT) and run the dense encoder GEMM into pre [B][H]
+int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,
+                                 int B, float* pre, hipStream_t st);

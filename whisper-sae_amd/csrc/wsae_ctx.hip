@@ -153,6 +153,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
 extern "C" int wsae_ctx_destroy(wsae_ctx* ctx) {
     if (!ctx) return WSAE_OK;
     prof_free(ctx);
+    if (ctx->relu_ws) (void)hipFree(ctx->relu_ws);
     if (ctx->We_bf16) (void)hipFree((void*)ctx->We_bf16);  // base of the single allocation
     delete ctx;
     return WSAE_OK;

@@ -1042,6 +1042,12 @@ static int check_batch(const wsae_ctx* c, const void* x, int x_dtype, int B, con
     return WSAE_OK;
 }
 
+int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,
+                                 int B, float* pre, hipStream_t st) {
+    return ctx->prec == WSAE_PREC_BF16 ? stage_and_gemm<bf16_t>(ctx, params, x, x_dtype, rows, B, pre, st)
+                                       : stage_and_gemm<float>(ctx, params, x, x_dtype, rows, B, pre, st);
+}
+
 extern "C" int wsae_encode_dense(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                                  const int32_t* rows, int32_t B, float* pre, void* stream) {
     int rc = check_batch(ctx, x, x_dtype, B, "wsae_encode_dense");

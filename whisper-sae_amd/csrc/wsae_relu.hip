@@ -1,15 +1,450 @@
-// ReLU SAE dense path (model.py:260-322).  Scheduled after the TopK path (SURVEY.md section 7,
-// stage 8); the entry points exist so the ABI is stable and fail loudly until the kernels land.
+// ReLU + L1 sparse autoencoder, dense path (reference ReLUSAE, model.py:260-322).
+//   forward : hidden = relu(x W_e^T + b_e) ; recon = hidden W_d^T + b_d
+//             loss = mean((recon - x)^2) + sparsity_weight * mean(|hidden|)      (means over B*D and B*H)
+//   backward: g = 2 (recon - x) / (B D) ; dW_d = g^T hidden ; db_d = sum_b g
+//             dpre = (g W_d + sparsity_weight / (B H)) * 1[hidden > 0]
+//             dW_e = dpre^T x ; db_e = sum_b dpre                                 (no dL/dx: five GEMM passes)
+// The module has no pre-bias: it runs on the TopK parameter pack with b_pre = 0 (include/wsae.h), so the
+// staging kernel, the encoder GEMM, the optimizer tail and the decoder renorm are the TopK path's own.
+// Everything dense goes through ONE generic NT MFMA GEMM (C = A Bt^T, K contiguous in both operands,
+// optional split-K into slabs); the element-wise kernels in between also write the transposed copies
+// the next GEMM needs as its K-contiguous operand, through 64 x 64 LDS tiles.  No float atomics: every
+// reduction is a two-level partial sum in fixed order.
 #include "wsae_common.h"
+#include "wsae_mfma.h"
 
-extern "C" int wsae_relu_forward(wsae_ctx*, const float*, const void*, int32_t, const int32_t*, int32_t, float, float*,
-                                 float*, wsae_stats*, float*, void*) {
-    wsae_set_error("wsae_relu_forward: the ReLU SAE kernels are not part of this build yet");
-    return WSAE_ERR_INVALID;
+namespace {
+
+// ---- workspace -----------------------------------------------------------------------------------
+struct ReluWs {
+    void* hid;      // [maxB][H]   hidden in the contraction dtype (A operand of the decoder GEMM)
+    void* hidT;     // [H][ldT]    its transpose (A operand of dW_d)
+    void* dpreT;    // [H][ldT]    dpre transposed (A operand of dW_e)
+    void* wd_nt;    // [D][H]      decoder weight in the reference's [D, H] layout (Bt operand of the decoder GEMM)
+    float* part;    // [3][nblk]   per-tile partial sums: |hidden|, count(hidden > 0), squared residual
+    float* colpart; // [ceil(maxB/64)][H]  per-tile column sums of dpre (db_e)
+    float* scal;    // [4]         sparsity, mse
+    int nblk;
+};
+
+int ensure_ws(wsae_ctx* c) {
+    if (c->relu_ws) return WSAE_OK;
+    const size_t es = c->prec == WSAE_PREC_BF16 ? 2 : 4;
+    const size_t ldT = ((size_t)c->maxB + 127) / 128 * 128;
+    const size_t H = c->H, D = c->D, nb = (ldT + 63) / 64;
+    const size_t nblk = nb * ((max(H, D) + 63) / 64);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o0 = up(sizeof(ReluWs));
+    const size_t o1 = o0 + up(ldT * H * es);
+    const size_t o2 = o1 + up(H * ldT * es);
+    const size_t o3 = o2 + up(H * ldT * es);
+    const size_t o4 = o3 + up(D * H * es);
+    const size_t o5 = o4 + up(3 * nblk * 4);
+    const size_t o6 = o5 + up(nb * H * 4);
+    const size_t total = o6 + 256;
+    char* base = nullptr;
+    if (hipMalloc((void**)&base, total) != hipSuccess) {
+        wsae_set_error("wsae_relu: cannot allocate the %zu-byte ReLU workspace", total);
+        return WSAE_ERR_HIP;
+    }
+    ReluWs h;
+    h.hid = base + o0; h.hidT = base + o1; h.dpreT = base + o2; h.wd_nt = base + o3;
+    h.part = (float*)(base + o4); h.colpart = (float*)(base + o5); h.scal = (float*)(base + o6);
+    h.nblk = (int)nblk;
+    if (hipMemset(base, 0, total) != hipSuccess || hipMemcpy(base, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(base);
+        wsae_set_error("wsae_relu: workspace initialisation failed");
+        return WSAE_ERR_HIP;
+    }
+    c->relu_ws = base;
+    return WSAE_OK;
 }
 
-extern "C" int wsae_relu_backward(wsae_ctx*, const float*, const void*, int32_t, const int32_t*, int32_t, float,
-                                  const float*, const float*, float*, void*) {
-    wsae_set_error("wsae_relu_backward: the ReLU SAE kernels are not part of this build yet");
-    return WSAE_ERR_INVALID;
+ReluWs host_ws(wsae_ctx* c) {  // the descriptor is also kept at the head of the allocation; rebuild it on the host
+    const size_t es = c->prec == WSAE_PREC_BF16 ? 2 : 4;
+    const size_t ldT = ((size_t)c->maxB + 127) / 128 * 128;
+    const size_t H = c->H, D = c->D, nb = (ldT + 63) / 64;
+    const size_t nblk = nb * ((max(H, D) + 63) / 64);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    char* base = (char*)c->relu_ws;
+    size_t o = up(sizeof(ReluWs));
+    ReluWs h;
+    h.hid = base + o; o += up(ldT * H * es);
+    h.hidT = base + o; o += up(H * ldT * es);
+    h.dpreT = base + o; o += up(H * ldT * es);
+    h.wd_nt = base + o; o += up(D * H * es);
+    h.part = (float*)(base + o); o += up(3 * nblk * 4);
+    h.colpart = (float*)(base + o); o += up(nb * H * 4);
+    h.scal = (float*)(base + o);
+    h.nblk = (int)nblk;
+    return h;
+}
+
+// ---- generic NT GEMM: C[M][N] (+ z * cz) = A[M][K] . Bt[N][K]^T over K range z (+ bias[n] on z = 0) -------
+template <typename T>
+__global__ void __launch_bounds__(256)
+gemm_nt_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ Bt, int64_t ldb,
+               const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int M, int N, int K, int kper,
+               int64_t cz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + TILE_LDS_BYTES;
+    constexpr int KT = Mfma<T>::KT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * TILE_M, n0 = blockIdx.x * TILE_N;
+    const int k_begin = blockIdx.z * kper, k_end = min(K, k_begin + kper);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    SlabRegs<T> ra, rb;
+    if (k_begin < k_end) {
+        slab_load<T>(ra, A, lda, m0, M, k_begin, k_end, tid);
+        slab_load<T>(rb, Bt, ldb, n0, N, k_begin, k_end, tid);
+    }
+    for (int k = k_begin; k < k_end; k += KT) {
+        slab_store<T>(ra, As, tid);
+        slab_store<T>(rb, Bs, tid);
+        __syncthreads();
+        if (k + KT < k_end) {
+            slab_load<T>(ra, A, lda, m0, M, k + KT, k_end, tid);
+            slab_load<T>(rb, Bt, ldb, n0, N, k + KT, k_end, tid);
+        }
+        Mfma<T>::slab(As, Bs, wm * 64, wn * 64, lane, acc);
+        __syncthreads();
+    }
+    float* Cz = C + (int64_t)blockIdx.z * cz;
+    const int col = lane & 31, rq = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wn * 64 + ni * 32 + col;
+            if (n >= N) continue;
+            const float bv = (bias && blockIdx.z == 0) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                if (m < M) Cz[(int64_t)m * ldc + n] = acc[mi][ni][r] + bv;
+            }
+        }
+}
+
+template <typename T>
+void gemm_nt(hipStream_t st, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias, float* C,
+             int64_t ldc, int M, int N, int K, int nz, int64_t cz) {
+    constexpr int KT = Mfma<T>::KT;
+    const int kper = ceil_div(ceil_div(K, nz), KT) * KT;
+    dim3 grid(ceil_div(N, TILE_N), ceil_div(M, TILE_M), ceil_div(K, kper));
+    gemm_nt_kernel<T><<<grid, 256, 2 * TILE_LDS_BYTES, st>>>((const T*)A, lda, (const T*)Bt, ldb, bias, C, ldc, M, N, K, kper, cz);
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float a, float b, float c, float d) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x4 o;
+        o[0] = (bf16_t)a; o[1] = (bf16_t)b; o[2] = (bf16_t)c; o[3] = (bf16_t)d;
+        *(bf16x4*)p = o;
+    } else {
+        *(float4*)p = make_float4(a, b, c, d);
+    }
+}
+
+// ---- W_dT [H][D] (shadow or master) -> wd_nt [D][H] ------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_w_kernel(const T* __restrict__ src, T* __restrict__ dst, int H, int D) {
+    __shared__ float tile[64][65];
+    const int h0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int hl = i >> 6, dl = i & 63;
+        tile[hl][dl] = (h0 + hl < H && d0 + dl < D) ? (float)src[(int64_t)(h0 + hl) * D + d0 + dl] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int dl = i >> 6, hl = i & 63;
+        if (h0 + hl < H && d0 + dl < D) dst[(int64_t)(d0 + dl) * H + h0 + hl] = (T)tile[hl][dl];
+    }
+}
+
+// ---- hidden = relu(pre): f32 API copy, contraction-dtype copy, transposed copy, L1 / l0 partials ------
+template <typename T>
+__global__ void __launch_bounds__(256)
+relu_act_kernel(const float* __restrict__ pre, float* __restrict__ hidden, T* __restrict__ hid, T* __restrict__ hidT,
+                int B, int H, int ldT, float* __restrict__ part, int nblk) {
+    __shared__ float tile[64][65];
+    __shared__ float red[8];
+    const int h0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+    float s = 0.f, c = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int bl = r16 + 16 * p, b = b0 + bl, h = h0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B && h < H) {
+            v = *(const float4*)(pre + (int64_t)b * H + h);
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            *(float4*)(hidden + (int64_t)b * H + h) = v;
+            store4<T>(hid + (int64_t)b * H + h, v.x, v.y, v.z, v.w);
+            s += (v.x + v.y) + (v.z + v.w);
+            c += (float)((v.x > 0.f) + (v.y > 0.f) + (v.z > 0.f) + (v.w > 0.f));
+        }
+        tile[bl][4 * q] = v.x; tile[bl][4 * q + 1] = v.y; tile[bl][4 * q + 2] = v.z; tile[bl][4 * q + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int hl = r16 + 16 * p, h = h0 + hl, b = b0 + 4 * q;
+        if (h < H && b < ldT)
+            store4<T>(hidT + (int64_t)h * ldT + b, tile[4 * q][hl], tile[4 * q + 1][hl], tile[4 * q + 2][hl], tile[4 * q + 3][hl]);
+    }
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    const float ts = block_sum(s, red);
+    const float tc = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        part[blk] = ts;
+        part[nblk + blk] = tc;
+    }
+}
+
+// ---- residual: loss partials; in backward also g (contraction dtype, row-major into xb), gT, db_d partials ----
+template <typename T, int XDT, bool BWD>
+__global__ void __launch_bounds__(256)
+resid_kernel(const float* __restrict__ recon, const void* __restrict__ x, const int32_t* __restrict__ rows, int B, int D,
+             int ldT, float scale, T* __restrict__ g_rm, T* __restrict__ gT, float* __restrict__ part_dbd,
+             float* __restrict__ part_loss) {
+    __shared__ float tile[64][65];
+    __shared__ float red[8];
+    const int d0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+    float loss = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int bl = r16 + 16 * p, b = b0 + bl, d = d0 + 4 * q;
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (b < B && d < D) {
+            const int64_t src = rows ? (int64_t)rows[b] : (int64_t)b;
+            const float4 rc = *(const float4*)(recon + (int64_t)b * D + d);
+            r[0] = rc.x - load_act<XDT>(x, src * D + d);
+            r[1] = rc.y - load_act<XDT>(x, src * D + d + 1);
+            r[2] = rc.z - load_act<XDT>(x, src * D + d + 2);
+            r[3] = rc.w - load_act<XDT>(x, src * D + d + 3);
+            loss += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+            if (BWD) store4<T>(g_rm + (int64_t)b * D + d, r[0] * scale, r[1] * scale, r[2] * scale, r[3] * scale);
+        }
+        if (BWD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tile[bl][4 * q + i] = r[i] * scale;
+        }
+    }
+    if (BWD) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int dl = r16 + 16 * p, d = d0 + dl, b = b0 + 4 * q;
+            if (d < D && b < ldT)
+                store4<T>(gT + (int64_t)d * ldT + b, tile[4 * q][dl], tile[4 * q + 1][dl], tile[4 * q + 2][dl], tile[4 * q + 3][dl]);
+        }
+        if (threadIdx.x < 64 && d0 + (int)threadIdx.x < D) {  // column sums of this tile's 64 rows, fixed order
+            float a = 0.f;
+            for (int bl = 0; bl < 64; ++bl) a += tile[bl][threadIdx.x];
+            part_dbd[(int64_t)blockIdx.y * D + d0 + threadIdx.x] = a;
+        }
+    }
+    const float t = block_sum(loss, red);
+    if (threadIdx.x == 0) part_loss[blockIdx.y * gridDim.x + blockIdx.x] = t;
+}
+
+// ---- dpre = (dh + l1) * 1[hidden > 0] -> dpreT, db_e partials ----------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+dpre_kernel(const float* __restrict__ dh, const float* __restrict__ hidden, int B, int H, int ldT, float l1,
+            T* __restrict__ dpreT, float* __restrict__ colpart) {
+    __shared__ float tile[64][65];
+    const int h0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int bl = r16 + 16 * p, b = b0 + bl, h = h0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B && h < H) {
+            const float4 d4 = *(const float4*)(dh + (int64_t)b * H + h);
+            const float4 h4 = *(const float4*)(hidden + (int64_t)b * H + h);
+            v.x = h4.x > 0.f ? d4.x + l1 : 0.f;
+            v.y = h4.y > 0.f ? d4.y + l1 : 0.f;
+            v.z = h4.z > 0.f ? d4.z + l1 : 0.f;
+            v.w = h4.w > 0.f ? d4.w + l1 : 0.f;
+        }
+        tile[bl][4 * q] = v.x; tile[bl][4 * q + 1] = v.y; tile[bl][4 * q + 2] = v.z; tile[bl][4 * q + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int hl = r16 + 16 * p, h = h0 + hl, b = b0 + 4 * q;
+        if (h < H && b < ldT)
+            store4<T>(dpreT + (int64_t)h * ldT + b, tile[4 * q][hl], tile[4 * q + 1][hl], tile[4 * q + 2][hl], tile[4 * q + 3][hl]);
+    }
+    if (threadIdx.x < 64 && h0 + (int)threadIdx.x < H) {
+        float a = 0.f;
+        for (int bl = 0; bl < 64; ++bl) a += tile[bl][threadIdx.x];
+        colpart[(int64_t)blockIdx.y * H + h0 + threadIdx.x] = a;
+    }
+}
+
+// ---- small finishing kernels (fixed summation order) ---------------------------------------------------
+__global__ void __launch_bounds__(256)
+relu_fwd_finish_kernel(const float* __restrict__ part, int nblk_act, int nblk_res, int nblk, int B, int D, int H,
+                       float weight, wsae_stats* __restrict__ stats, float* __restrict__ sparsity_out,
+                       float* __restrict__ scal) {
+    __shared__ float red[8];
+    float s = 0.f, c = 0.f, l = 0.f;
+    for (int i = threadIdx.x; i < nblk_act; i += 256) {
+        s += part[i];
+        c += part[nblk + i];
+    }
+    for (int i = threadIdx.x; i < nblk_res; i += 256) l += part[2 * nblk + i];
+    const float ts = block_sum(s, red), tc = block_sum(c, red), tl = block_sum(l, red);
+    if (threadIdx.x == 0) {
+        const float sparsity = ts / ((float)B * (float)H);
+        const float mse = tl / ((float)B * (float)D);
+        scal[0] = sparsity;
+        scal[1] = mse;
+        if (sparsity_out) *sparsity_out = sparsity;
+        if (stats) {
+            stats->loss = mse + weight * sparsity;
+            stats->l0 = tc / (float)B;
+            stats->reserved = __float_as_int(sparsity);  // TrainingMetrics: reconstruction = loss - weight * sparsity
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ part, int nrows, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f;
+    for (int i0 = 0; i0 < nrows; i0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (i0 + i < nrows) ? part[(int64_t)min(i0 + i, nrows - 1) * N + n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += v[i];
+    }
+    out[n] = a;
+}
+
+__global__ void __launch_bounds__(256)
+slab_sum_kernel(const float* __restrict__ slabs, int64_t slab_stride, int nz, int64_t n4, float* __restrict__ grads,
+                float* __restrict__ g_bpre, int D) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 a = ((const float4*)slabs)[i];
+        for (int z = 1; z < nz; ++z) {
+            const float4 b = ((const float4*)(slabs + z * slab_stride))[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        ((float4*)grads)[i] = a;
+    }
+    if (blockIdx.x == 0)
+        for (int d = threadIdx.x; d < D; d += 256) g_bpre[d] = 0.f;  // no pre-bias in this module: it stays exactly 0
+}
+
+int check_dims(wsae_ctx* ctx, int B, const char* who) {
+    WSAE_REQUIRE(B >= 1 && B <= ctx->maxB, "%s: batch %d outside [1, %d]", who, B, ctx->maxB);
+    WSAE_REQUIRE(ctx->D % 8 == 0 && ctx->H % 8 == 0, "%s: input_dim %d and hidden_dim %d must be multiples of 8", who, ctx->D,
+                 ctx->H);
+    WSAE_REQUIRE(ceil_div(B, 64) <= WSAE_MAX_PARTIALS, "%s: batch %d too large for the bias-gradient partials", who, B);
+    return WSAE_OK;
+}
+
+template <typename T>
+int forward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, float weight,
+              float* hidden, float* recon, wsae_stats* stats, float* sparsity_out, hipStream_t st) {
+    const int D = ctx->D, H = ctx->H;
+    const int ldT = (B + 127) / 128 * 128;
+    const ReluWs ws = host_ws(ctx);
+    int rc = wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, st);  // pre = x W_e^T + b_e
+    if (rc) return rc;
+    const T* wdt = sizeof(T) == 2 ? (const T*)ctx->WdT_bf16 : (const T*)(params + ctx->off[1]);
+    transpose_w_kernel<T><<<dim3(ceil_div(H, 64), ceil_div(D, 64)), 256, 0, st>>>(wdt, (T*)ws.wd_nt, H, D);
+    dim3 ga(ceil_div(H, 64), ceil_div(ldT, 64));
+    relu_act_kernel<T><<<ga, 256, 0, st>>>(ctx->pre, hidden, (T*)ws.hid, (T*)ws.hidT, B, H, ldT, ws.part, ws.nblk);
+    gemm_nt<T>(st, ws.hid, H, ws.wd_nt, H, params + ctx->off[3], recon, D, B, D, H, 1, 0);  // recon = hidden W_d^T + b_d
+    dim3 gr(ceil_div(D, 64), ceil_div(ldT, 64));
+    if (x_dtype == WSAE_DT_F32)
+        resid_kernel<T, WSAE_DT_F32, false><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, 0.f, nullptr, nullptr, nullptr,
+                                                               ws.part + 2 * ws.nblk);
+    else
+        resid_kernel<T, WSAE_DT_BF16, false><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, 0.f, nullptr, nullptr, nullptr,
+                                                                ws.part + 2 * ws.nblk);
+    relu_fwd_finish_kernel<<<1, 256, 0, st>>>(ws.part, (int)(ga.x * ga.y), (int)(gr.x * gr.y), ws.nblk, B, D, H, weight,
+                                              stats, sparsity_out, ws.scal);
+    WSAE_LAUNCH_CHECK();
+    return WSAE_OK;
+}
+
+template <typename T>
+int backward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, float weight,
+               const float* hidden, const float* recon, float* grads, hipStream_t st) {
+    const int D = ctx->D, H = ctx->H;
+    const int ldT = (B + 127) / 128 * 128;
+    const ReluWs ws = host_ws(ctx);
+    const float scale = 2.0f / ((float)B * (float)D);
+    dim3 gr(ceil_div(D, 64), ceil_div(ldT, 64));
+    // g (row-major, into the staging buffer xb: the encoder GEMM is done with it), gT, db_d partials
+    if (x_dtype == WSAE_DT_F32)
+        resid_kernel<T, WSAE_DT_F32, true><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, scale, (T*)ctx->xb, (T*)ctx->gT,
+                                                              ctx->part_dbd, ws.part + 2 * ws.nblk);
+    else
+        resid_kernel<T, WSAE_DT_BF16, true><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, scale, (T*)ctx->xb, (T*)ctx->gT,
+                                                               ctx->part_dbd, ws.part + 2 * ws.nblk);
+    const T* wdt = sizeof(T) == 2 ? (const T*)ctx->WdT_bf16 : (const T*)(params + ctx->off[1]);
+    gemm_nt<T>(st, ctx->xb, D, wdt, D, nullptr, ctx->pre, H, B, H, D, 1, 0);  // dh = g W_d  [B][H]
+    dim3 ga(ceil_div(H, 64), ceil_div(ldT, 64));
+    dpre_kernel<T><<<ga, 256, 0, st>>>(ctx->pre, hidden, B, H, ldT, weight / ((float)B * (float)H), (T*)ws.dpreT, ws.colpart);
+    // split-K contractions over the batch into the slabs: [z][ dW_e (H*D) | dW_dT (H*D) ]
+    const int nz = min(WSAE_WGRAD_MAX_SPLIT, max(1, ldT / 512));
+    const int64_t hd = (int64_t)H * D, slab_stride = 2 * hd;
+    gemm_nt<T>(st, ws.dpreT, ldT, ctx->xT, ldT, nullptr, ctx->wg_slabs, D, H, D, ldT, nz, slab_stride);
+    gemm_nt<T>(st, ws.hidT, ldT, ctx->gT, ldT, nullptr, ctx->wg_slabs + hd, D, H, D, ldT, nz, slab_stride);
+    constexpr int KT = Mfma<T>::KT;
+    const int nz_eff = ceil_div(ldT, ceil_div(ceil_div(ldT, nz), KT) * KT);
+    slab_sum_kernel<<<512, 256, 0, st>>>(ctx->wg_slabs, slab_stride, nz_eff, slab_stride / 4, grads, grads + ctx->off[4], D);
+    colsum_kernel<<<ceil_div(H, 256), 256, 0, st>>>(ws.colpart, ceil_div(B, 64), H, grads + ctx->off[2]);
+    colsum_kernel<<<ceil_div(D, 256), 256, 0, st>>>(ctx->part_dbd, ceil_div(B, 64), D, grads + ctx->off[3]);
+    WSAE_LAUNCH_CHECK();
+    ctx->n_sq_parts = 0;  // the optimizer computes the norm itself (norm_from_wgrad = 0)
+    return WSAE_OK;
+}
+
+}  // namespace
+
+extern "C" int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,
+                                 int32_t B, float sparsity_weight, float* hidden, float* recon, wsae_stats* stats,
+                                 float* sparsity_loss_out, void* stream) {
+    WSAE_REQUIRE(ctx && params && x && hidden && recon, "wsae_relu_forward: null argument");
+    WSAE_REQUIRE(x_dtype == WSAE_DT_F32 || x_dtype == WSAE_DT_BF16, "wsae_relu_forward: unknown activation dtype %d", x_dtype);
+    int rc = check_dims(ctx, B, "wsae_relu_forward");
+    if (rc) return rc;
+    rc = ensure_ws(ctx);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return ctx->prec == WSAE_PREC_BF16
+               ? forward_t<bf16_t>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, stats, sparsity_loss_out, st)
+               : forward_t<float>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, stats, sparsity_loss_out, st);
+}
+
+extern "C" int wsae_relu_backward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,
+                                  int32_t B, float sparsity_weight, const float* hidden, const float* recon, float* grads,
+                                  void* stream) {
+    WSAE_REQUIRE(ctx && params && x && hidden && recon && grads, "wsae_relu_backward: null argument");
+    WSAE_REQUIRE(x_dtype == WSAE_DT_F32 || x_dtype == WSAE_DT_BF16, "wsae_relu_backward: unknown activation dtype %d", x_dtype);
+    int rc = check_dims(ctx, B, "wsae_relu_backward");
+    if (rc) return rc;
+    WSAE_REQUIRE(ctx->relu_ws, "wsae_relu_backward: no preceding wsae_relu_forward on this ctx");
+    hipStream_t st = (hipStream_t)stream;
+    return ctx->prec == WSAE_PREC_BF16
+               ? backward_t<bf16_t>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, grads, st)
+               : backward_t<float>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, grads, st);
 }

@@ -42,7 +42,7 @@ class SAEEngine:
         self._ctx: dict[int, tuple[int, int]] = {}  # precision -> (handle, max_batch)
         self._fresh: dict[int, bool] = {}  # precision -> derived shadows match the pack
         self.stats = torch.zeros(N.STATS_WORDS, dtype=torch.int32, device=self.device)
-        self._work: dict[int, dict] = {}
+        self._work: dict = {}
         self.generation = 0  # bumped by every forward that leaves g / xT / gT in the ctx
 
     # -- pack views ----------------------------------------------------------------------------
@@ -110,6 +110,16 @@ class SAEEngine:
                 "dpre": torch.empty(batch, self.k, dtype=torch.float32, device=self.device),
             }
             self._work[batch] = w
+        return w
+
+    def relu_work(self, batch: int) -> dict:
+        w = self._work.get(("relu", batch))
+        if w is None:
+            if len(self._work) > 4:
+                self._work.clear()
+            w = {"hidden": torch.empty(batch, self.H, dtype=torch.float32, device=self.device),
+                 "recon": torch.empty(batch, self.D, dtype=torch.float32, device=self.device)}
+            self._work[("relu", batch)] = w
         return w
 
     def stats_f32(self) -> torch.Tensor:

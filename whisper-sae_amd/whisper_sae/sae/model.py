@@ -333,35 +333,136 @@ class TopKSAE(nn.Module):
         return f"input_dim={self.input_dim}, hidden_dim={self.hidden_dim}, k={self.k}"
 
 
+class _ReLUForward(torch.autograd.Function):
+    """wsae_relu_forward (-> wsae_relu_backward) as one autograd node; gradients are defined for ``loss``
+    with respect to the four parameters (the reference computes no ``dL/dx`` either)."""
+
+    @staticmethod
+    def forward(ctx, x, w_e, b_e, w_d, b_d, module, prec):
+        eng: SAEEngine = module._engine
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, eng.D)
+        if x2.dtype not in (torch.float32, torch.bfloat16):
+            x2 = x2.float()
+        x2 = x2.contiguous()
+        B = x2.shape[0]
+        handle = eng.prepare(prec, B, force=True)
+        hidden = torch.empty(B, eng.H, dtype=torch.float32, device=eng.device)
+        recon = torch.empty(B, eng.D, dtype=torch.float32, device=eng.device)
+        sparsity = torch.empty((), dtype=torch.float32, device=eng.device)
+        N.check(eng.lib.wsae_relu_forward(handle, eng.pack.data_ptr(), x2.data_ptr(), _dtype_code(x2), 0, B,
+                                          float(module.sparsity_weight), hidden.data_ptr(), recon.data_ptr(),
+                                          eng.stats.data_ptr(), sparsity.data_ptr(), eng.stream()), "wsae_relu_forward")
+        sf = eng.stats_f32()
+        loss, l0 = sf[0].clone(), sf[1].clone()
+        eng.generation += 1
+        ctx.module, ctx.prec, ctx.gen, ctx.B = module, prec, eng.generation, B
+        ctx.save_for_backward(x2, hidden, recon)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(recon, hidden, sparsity, l0)
+        return recon.reshape(*lead, eng.D), hidden.reshape(*lead, eng.H), loss, sparsity, l0
+
+    @staticmethod
+    def backward(ctx, g_recon, g_hidden, g_loss, g_sparsity, g_l0):
+        if g_loss is None:
+            return (None,) * 7
+        module, prec, B = ctx.module, ctx.prec, ctx.B
+        eng: SAEEngine = module._engine
+        x2, hidden, recon = ctx.saved_tensors
+        handle = eng.prepare(prec, B, force=True)
+        pk, xd, st = eng.pack.data_ptr(), _dtype_code(x2), eng.stream()
+        w = float(module.sparsity_weight)
+        if eng.generation != ctx.gen:  # another forward reused the ctx workspace since: rebuild xT / hidden^T for this batch
+            h2, r2 = torch.empty_like(hidden), torch.empty_like(recon)
+            N.check(eng.lib.wsae_relu_forward(handle, pk, x2.data_ptr(), xd, 0, B, w, h2.data_ptr(), r2.data_ptr(), 0, 0,
+                                              st), "wsae_relu_forward")
+            eng.generation += 1
+        grads = torch.empty(eng.P, dtype=torch.float32, device=eng.device)
+        N.check(eng.lib.wsae_relu_backward(handle, pk, x2.data_ptr(), xd, 0, B, w, hidden.data_ptr(), recon.data_ptr(),
+                                           grads.data_ptr(), st), "wsae_relu_backward")
+        grads.mul_(g_loss)
+        need = ctx.needs_input_grad
+        gv = lambda name, on: eng.view(name, grads) if on else None  # noqa: E731
+        return (None, gv("encoder.weight", need[1]), gv("encoder.bias", need[2]), gv("decoder.weight", need[3]),
+                gv("decoder.bias", need[4]), None, None)
+
+
 class ReLUSAE(nn.Module):
     """ReLU + L1 sparse autoencoder (reference model.py:260-322).
 
-    No ``b_pre``, default ``nn.Linear`` initialisation with (optionally) unit-norm decoder columns.
-    Unlike the reference (whose trainer crashes on it) it can be trained by
-    ``SAETrainer``: the trainer simply skips dead-feature bookkeeping for modules without it.
+    No ``b_pre``, default ``nn.Linear`` initialisation with (optionally) unit-norm decoder columns; the
+    loss is ``mse + sparsity_weight * mean|hidden|``.  The kernels (``wsae_relu_forward/backward``) run on
+    the TopK parameter pack with the pre-bias slot held at zero.  Unlike the reference (whose trainer
+    crashes on it) it can be trained by ``SAETrainer``: there is no dead-feature
+    bookkeeping for this module, as in the reference.
     """
 
+    is_relu = True
+
     def __init__(self, input_dim: int, hidden_dim: int, sparsity_weight: float = 0.01,
-                 normalize_decoder: bool = True):
+                 normalize_decoder: bool = True, precision: Optional[str] = None):
         super().__init__()
         self.input_dim = input_dim
         self.hidden_dim = hidden_dim
         self.sparsity_weight = sparsity_weight
         self.normalize_decoder = normalize_decoder
+        self.precision = precision
         self.encoder = nn.Linear(input_dim, hidden_dim)
         self.decoder = nn.Linear(hidden_dim, input_dim)
         if normalize_decoder:
-            with torch.no_grad():
+            with torch.no_grad():  # reference model.py:285-286 (F.normalize(dim=0))
                 w = self.decoder.weight.data
                 self.decoder.weight.data = w / w.norm(dim=0, keepdim=True).clamp_min(1e-12)
+        self._engine: Optional[SAEEngine] = None
+
+    def _named_core_params(self):
+        return {"encoder.weight": self.encoder.weight, "decoder.weight": self.decoder.weight,
+                "encoder.bias": self.encoder.bias, "decoder.bias": self.decoder.bias}
+
+    def bind(self) -> SAEEngine:
+        """Make the four parameters views of one device pack (the pre-bias slot of the pack stays zero)."""
+        dev = self.encoder.weight.device
+        require_device_tensor(self.encoder.weight, "ReLUSAE")
+        eng = self._engine
+        if eng is None or eng.device != dev:
+            if eng is not None:
+                eng.close()
+            eng = SAEEngine(dev, self.input_dim, self.hidden_dim, 1)
+            self._engine = eng
+        with torch.no_grad():
+            for name, p in self._named_core_params().items():
+                v = eng.view(name)
+                if p.data_ptr() != v.data_ptr() or p.shape != v.shape or p.stride() != v.stride():
+                    v.copy_(p.detach().to(device=dev, dtype=torch.float32))
+                    p.data = v
+                    eng.invalidate()
+        return eng
+
+    def param_token(self) -> tuple:
+        return tuple((p.data_ptr(), p._version) for p in self._named_core_params().values())
 
     def normalize_decoder_weights(self) -> None:
-        if self.normalize_decoder:
-            raise N.WsaeError("ReLUSAE kernels are not part of this build yet (wsae_relu_forward)")
+        """Unit-norm decoder columns when ``normalize_decoder`` is set (reference model.py:296-302)."""
+        if not self.normalize_decoder:
+            return
+        eng = self.bind()
+        handle = eng.ctx(_precision_code(self.precision), 64)
+        N.check(eng.lib.wsae_normalize_decoder(handle, eng.pack.data_ptr(), eng.stream()), "wsae_normalize_decoder")
+        eng.invalidate()
 
     def forward(self, x: Tensor) -> SAEOutput:
+        """Reference model.py:304-322."""
+        self.bind()
         require_device_tensor(x, "input")
-        raise N.WsaeError("ReLUSAE kernels are not part of this build yet (wsae_relu_forward)")
+        prec = _precision_code(self.precision)
+        recon, hidden, loss, sparsity, l0 = _ReLUForward.apply(x, self.encoder.weight, self.encoder.bias,
+                                                               self.decoder.weight, self.decoder.bias, self, prec)
+        return SAEOutput(reconstructed=recon, hidden=hidden, loss=loss,
+                         reconstruction_loss=(loss - self.sparsity_weight * sparsity).detach(),
+                         sparsity_loss=sparsity, l0=l0)
+
+    def extra_repr(self) -> str:
+        return f"input_dim={self.input_dim}, hidden_dim={self.hidden_dim}, sparsity_weight={self.sparsity_weight}"
 
 
 def create_sae(config: SAEConfig, input_dim: int) -> nn.Module:

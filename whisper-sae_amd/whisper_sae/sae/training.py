@@ -59,7 +59,9 @@ class _PendingMetrics(TrainingMetrics):
 
     _LAZY = ("loss", "reconstruction_loss", "sparsity_loss", "l0", "dead_feature_ratio")
 
-    def __init__(self, chunk: "_RecordChunk", slot: int, stream, learning_rate: float, step: int):  # noqa: D401
+    def __init__(self, chunk: "_RecordChunk", slot: int, stream, learning_rate: float, step: int,
+                 sparsity_weight: float = 0.0):  # noqa: D401
+        object.__setattr__(self, "_weight", sparsity_weight)
         object.__setattr__(self, "_chunk", chunk)
         object.__setattr__(self, "_slot", slot)
         object.__setattr__(self, "_stream", stream)
@@ -71,7 +73,10 @@ class _PendingMetrics(TrainingMetrics):
         if chunk is None:
             return
         f = chunk.host_record(self.__dict__.pop("_slot"), self.__dict__.pop("_stream"))
-        self.__dict__.update(loss=float(f[0]), reconstruction_loss=float(f[0]), sparsity_loss=0.0, l0=float(f[1]),
+        w = self.__dict__.pop("_weight", 0.0)
+        sparsity = float(f[7]) if w else 0.0  # wsae_stats.reserved carries mean|hidden| on the ReLU path
+        self.__dict__.update(loss=float(f[0]), reconstruction_loss=float(f[0]) - w * sparsity, sparsity_loss=sparsity,
+                             l0=float(f[1]),
                              dead_feature_ratio=float(f[4]), grad_norm=float(f[2]), clip_coef=float(f[3]))
 
     def __getattr__(self, name):  # only reached for attributes not yet in __dict__
@@ -207,6 +212,8 @@ class SAETrainer:
         handle = eng.prepare(prec, B)
         opt = self.optimizer
         opt._ensure_state(eng)
+        if getattr(model, "is_relu", False):
+            return self._train_step_relu(model, eng, handle, opt, x, rows, B, prec)
         w = eng.work(B)
         pk, xd, rp = eng.pack.data_ptr(), _dtype_code(x), N.ptr(rows)
         chunk, slot = self._records.next(eng.device)
@@ -237,6 +244,30 @@ class SAETrainer:
         if self.resample_dead:
             self._maybe_resample_dead_features()
         return metrics
+
+    def _train_step_relu(self, model, eng, handle, opt, x, rows, B, prec) -> TrainingMetrics:
+        """ReLU + L1 step (reference ReLUSAE under training.py:161-217; no dead-feature bookkeeping)."""
+        lib, st = eng.lib, eng.stream()
+        w = eng.relu_work(B)
+        pk, xd, rp = eng.pack.data_ptr(), _dtype_code(x), N.ptr(rows)
+        chunk, slot = self._records.next(eng.device)
+        stats = chunk.dev.data_ptr() + slot * N.STATS_WORDS * 4
+        weight = float(model.sparsity_weight)
+        N.check(lib.wsae_relu_forward(handle, pk, x.data_ptr(), xd, rp, B, weight, w["hidden"].data_ptr(),
+                                      w["recon"].data_ptr(), stats, 0, st), "wsae_relu_forward")
+        N.check(lib.wsae_relu_backward(handle, pk, x.data_ptr(), xd, rp, B, weight, w["hidden"].data_ptr(),
+                                       w["recon"].data_ptr(), opt.grads.data_ptr(), st), "wsae_relu_backward")
+        eng.generation += 1
+        grad_scale = sync_gradients(opt.grads) if world()[1] > 1 else 1.0
+        opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=grad_scale,
+                 normalize_decoder=bool(model.normalize_decoder), batch=B, norm_from_wgrad=False, dead_scan=False,
+                 stats_ptr=stats)
+        self._token = model.param_token()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        self.global_step += 1
+        return _PendingMetrics(chunk, slot, torch.cuda.current_stream(eng.device), opt.param_groups[0]["lr"],
+                               self.global_step, sparsity_weight=weight)
 
     def train_epoch(self, dataloader, progress=None, task_id=None) -> list:
         """One pass over ``dataloader`` (reference training.py:219-259)."""
