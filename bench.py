@@ -75,6 +75,8 @@ def main() -> None:
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel (adds event overhead)")
+    ap.add_argument("--relu", action="store_true", help="informational: ReLU+L1 SAE step (row A12) instead of the TopK "
+                                                        "headline; no roofline object")
     args = ap.parse_args()
 
     import torch
@@ -83,7 +85,7 @@ def main() -> None:
     from whisper_sae import _native as N
     from whisper_sae.config import TrainingConfig
     from whisper_sae.data import ActivationRing, RingLoader
-    from whisper_sae.sae.model import TopKSAE
+    from whisper_sae.sae.model import ReLUSAE, TopKSAE
     from whisper_sae.sae.training import SAETrainer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,7 +101,7 @@ def main() -> None:
 
     B = args.batch
     torch.manual_seed(42)  # same initial weights on every rank (scripts/train.py:84-90 seeds before create_sae)
-    model = TopKSAE(D_MODEL, HIDDEN, k=TOPK)
+    model = ReLUSAE(D_MODEL, HIDDEN, sparsity_weight=0.01) if args.relu else TopKSAE(D_MODEL, HIDDEN, k=TOPK)
     cfg = TrainingConfig(batch_size=B, learning_rate=1e-4, weight_decay=0.0, warmup_steps=1000, gradient_clip=1.0,
                          use_amp=(args.precision == "bf16"), num_workers=0, seed=42)
     trainer = SAETrainer(model, cfg, device=device, run_dir=ROOT / "gpurun_out" / f"bench_rank{rank}")
@@ -150,7 +152,8 @@ def main() -> None:
 
     if rank == 0:
         value = world * B * args.steps / elapsed
-        f_dense = 12 * D_MODEL * HIDDEN  # flop per activation, the reference's 2 fwd + 4 bwd dense GEMMs
+        # flop per activation: the reference's 2 fwd + 4 bwd dense GEMMs (TopK), 2 + 3 without dL/dx (ReLU, row A12)
+        f_dense = (10 if args.relu else 12) * D_MODEL * HIDDEN
         # roofline of the dominant kernel: the two weight-gradient contractions, [H,B]x[B,D] each
         n_w, ms_w = prof.get("wgrad", (0, 0.0))
         roof = None
@@ -166,16 +169,18 @@ def main() -> None:
                     "step_dense_equiv_tflops": value * f_dense / 1e12,
                     "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS}
         out = {
-            "metric": "activations/sec through SAE train step (d=384->3072, k=32)",
+            "metric": "activations/sec through SAE train step (d=384->3072, " + ("relu+l1)" if args.relu else "k=32)"),
             "value": value, "unit": "activations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: TopKSAE 384->3072 k=32 train step, synthetic "
+            "config": {"workload": ("ReLUSAE 384->3072 (sparsity_weight 0.01) train step, informational" if args.relu else
+                                    "BASELINE.json configs[1]: TopKSAE 384->3072 k=32 train step") + ", synthetic "
                                    "activations resident in the HBM ring buffer" + ("" if world == 1 else
                                    f" (configs[2]: DDP x{world}, RCCL grad all-reduce)"),
                        "batch_per_gpu": B, "global_batch": world * B, "ring_rows_per_gpu": args.ring_rows,
                        "lr": 1e-4, "clip": 1.0, "parallelism": f"dp{world}"},
             "roofline": roof,
+            "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS,
             "final_loss": last.loss if last is not None else None,
         }
         if args.profile_all:

@@ -259,8 +259,14 @@ int wsae_profile_disable(wsae_ctx* ctx);
 int wsae_profile_read(wsae_ctx* ctx, int32_t kernel_id, int32_t* n_launches, double* total_ms);
 
 /* ---- ReLU SAE (model.py:260-322), dense path ------------------------------------------------- */
-/* params pack for ReLUSAE: [W_e H*D | W_dT H*D | b_e H | b_d D] (no b_pre; pass the TopK pack with
- * b_pre = 0 and relu=1).  hidden [B,H] f32 out; loss = mse + sparsity_weight * mean|hidden|. */
+/* ReLUSAE has no pre-bias: pass the TopK pack [W_e | W_dT | b_e | b_d | b_pre] with b_pre = 0 (wsae_prepare
+ * first, as for the TopK path).  forward:  hidden [B,H] f32 = relu(x W_e^T + b_e) (model.py:307),
+ * recon [B,D] f32 = hidden W_d^T + b_d (:308), stats->loss = mse + sparsity_weight * mean|hidden| (:309-311),
+ * stats->l0 (:313), stats->reserved = the float bits of mean|hidden|; *sparsity_loss_out likewise (may be
+ * NULL, as may stats).  backward (must follow the forward of the same batch on the same ctx: it reuses the
+ * staged x^T and hidden^T): grads in pack layout, dW_e, dW_dT, db_e, db_d as autograd of model.py:304-311
+ * gives them, the b_pre slot set to 0; no dL/dx (the reference has none either).  The first forward on a
+ * ctx allocates the dense workspace (3 x B x H operand copies) with hipMalloc; later calls allocate nothing. */
 int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                       const int32_t* rows, int32_t B, float sparsity_weight, float* hidden,
                       float* recon, wsae_stats* stats, float* sparsity_loss_out, void* stream);
