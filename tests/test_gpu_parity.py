@@ -444,6 +444,46 @@ class TestTopKKernel:
         assert np.array_equal(i, oi) and np.array_equal(v, ov)
 
 
+class TestTopKStrips:
+    """The strip-guided TopK kernel (batches >= 2048 with H % 256 == 0: the persistent GEMM leaves the maxima of
+    every 16-column strip, the TopK kernel reads only strips that can hold a winner) on rows built to stress it.
+    Every batch row gets the same pre-activations (zero encoder weights, the row lives in the bias)."""
+
+    def _run(self, device, row, K, precision):
+        from whisper_sae.sae.model import TopKSAE
+        H, D, B = row.shape[0], 64, 2048
+        m = TopKSAE(D, H, k=K, precision=precision).to(device)
+        with torch.no_grad():
+            m.encoder.weight.zero_()
+            m.b_pre.zero_()
+            m.encoder.bias.copy_(torch.from_numpy(row).to(device))
+        x = torch.from_numpy(synth.activations(B, D, seed=3, stream=1, bf16=True)).to(device)
+        v, i = m.encode_compact(x)
+        fb = int(m._engine.stats[6].item())
+        v, i = cpu(v), i.cpu().numpy()
+        assert (v == v[0]).all() and (i == i[0]).all()  # identical rows, identical answers
+        return v[0], i[0], fb
+
+    @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+    def test_stress_rows(self, device, precision):
+        H, K = 3072, 32
+        rng = synth.normal((H,), 9, 3)
+        rows = {
+            "random": rng,
+            "all_equal": np.full(H, 0.25, np.float32),                                  # every strip qualifies: exact path
+            "plateaus": np.repeat(np.arange(H // 512, dtype=np.float32), 512),           # 512 ties at the top
+            "one_strip": np.where(np.arange(H) // 16 == 77, 5.0 + np.arange(H) % 16, rng).astype(np.float32),
+            "winners_spread": np.where(np.arange(H) % 96 == 7, 9.0, rng).astype(np.float32),  # 32 winners, 32 strips
+            "negative": -np.abs(rng) - 1.0,
+        }
+        for name, row in rows.items():
+            v, i, fb = self._run(device, row.astype(np.float32), K, precision)
+            ov, oi = O.topk_select(row[None].astype(np.float32), K)
+            assert np.array_equal(i, oi[0]) and np.array_equal(v, ov[0]), name
+            if name in ("all_equal", "plateaus"):
+                assert fb >= 2048, name   # these rows cannot be settled by the strip filter
+
+
 class TestRing:
     def test_synthetic_fill_matches_oracle_generator(self, device):
         from whisper_sae.data import ActivationRing

@@ -79,6 +79,8 @@ struct wsae_ctx {
     void* gT;             // [D][maxB] g = 2(recon-x)/(BD) transposed, compute dtype
     float* g;             // [maxB][D] fp32 g (dx path, db_d)
     float* pre;           // [maxB][H] pre-activation scratch (TopK input)
+    float* smax;          // [maxB][H/16] maxima of the 16-column strips of pre (written by the persistent GEMM)
+    int smax_valid;       // 1 when smax matches the pre the last dense GEMM wrote
     float* part_loss;     // [WSAE_MAX_PARTIALS]
     float* part_l0;       // [WSAE_MAX_PARTIALS]
     float* part_dbd;      // [WSAE_MAX_PARTIALS][D]

@@ -77,6 +77,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     const size_t o_gT = cv.take(maxBp * D * esz);
     const size_t o_g = cv.take((size_t)maxB * D * 4);
     const size_t o_pre = cv.take((size_t)maxB * H * 4);
+    const size_t o_sm = cv.take((size_t)maxB * ((H + 15) / 16) * 4);
     const size_t o_pl = cv.take(WSAE_MAX_PARTIALS * 4);
     const size_t o_p0 = cv.take(WSAE_MAX_PARTIALS * 4);
     const size_t o_pd = cv.take((size_t)WSAE_MAX_PARTIALS * D * 4);
@@ -122,6 +123,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     c->gT = base + o_gT;
     c->g = (float*)(base + o_g);
     c->pre = (float*)(base + o_pre);
+    c->smax = (float*)(base + o_sm);
     c->part_loss = (float*)(base + o_pl);
     c->part_l0 = (float*)(base + o_p0);
     c->part_dbd = (float*)(base + o_pd);

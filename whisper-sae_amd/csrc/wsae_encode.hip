@@ -490,7 +490,8 @@ encode_rows_kernel(const T* __restrict__ xb, const T* __restrict__ W, const floa
 template <typename T>
 __global__ void __launch_bounds__(512)
 encode_gemm256p_kernel(const T* __restrict__ xb, const T* __restrict__ W, const float* __restrict__ bias,
-                       float* __restrict__ pre, int ldp, int B, int H, int D, int ntn, int ntiles) {
+                       float* __restrict__ pre, int ldp, int B, int H, int D, int ntn, int ntiles,
+                       float* __restrict__ smax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = Mfma<T>::KT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -568,6 +569,14 @@ encode_gemm256p_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
                 float4 v = *(const float4*)(patch + rl * PS + pc);
                 v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
                 if (b < B && hcol < H) *(float4*)(pre + (int64_t)b * ldp + hcol) = v;
+                if (smax) {
+                    // maximum of the 16-column strip this quad of lanes covers (two DPP quad permutes): the TopK
+                    // kernel reads these 4 bytes per 64 instead of the strip unless the strip can hold a winner
+                    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xF, 0xF, false)));
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xF, 0xF, false)));
+                    if ((lane & 3) == 0 && b < B && hcol < H) smax[(int64_t)b * (H >> 4) + (hcol >> 4)] = m;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -832,6 +841,98 @@ __device__ void topk_row_generic(const float* row, int H, int K, uint64_t* list,
 }
 
 // ------------------------------------------------------------------------------------------------
+// topk_strips_kernel: TopK guided by the strip maxima the GEMM epilogue leaves (smax [B][H/16]).
+//   T = K-th largest of the 64 lane maxima of the row's strip maxima: at least K strips - hence at least K
+//   distinct elements - are >= T, and every element >= T lives in a strip whose maximum is >= T.  So only
+//   those strips (typically K .. 1.5 K of the H/16) are read from the [B,H] matrix: 4 lanes x 16 bytes per
+//   strip, 16 strips per load instruction.  ~3 KB per row instead of 12 KB at H = 3072 - the same rows,
+//   the same keys, the same sort as topk_rows_kernel; anything unusual (more than TS_MAX_STRIPS candidate
+//   strips or TOPK_CAP candidates) goes to the exact full-row path.
+// ------------------------------------------------------------------------------------------------
+#define TS_MAX_STRIPS 128
+
+template <int SPL>  // strip maxima per lane: H / 16 <= 64 * SPL
+__global__ void __launch_bounds__(256)
+topk_strips_kernel(const float* __restrict__ pre, const float* __restrict__ smax, int B, int H, int K,
+                   float* __restrict__ vals, int32_t* __restrict__ idx, int64_t* __restrict__ step_count,
+                   int32_t* __restrict__ fallback_rows) {
+    __shared__ uint64_t lists[4][TOPK_CAP];
+    __shared__ int strips[4][TS_MAX_STRIPS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && step_count) *step_count += 1;  // model.py:175
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int ns = H >> 4;
+    const float* row = pre + (int64_t)b * H;
+    const float* srow = smax + (int64_t)b * ns;
+    uint64_t* list = lists[wave];
+    int* slist = strips[wave];
+    float* vrow = vals + (int64_t)b * K;
+    int32_t* irow = idx + (int64_t)b * K;
+
+    float sm[SPL];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const int s = lane + 64 * i;
+        sm[i] = s < ns ? srow[s] : -INFINITY;
+        m = fmaxf(m, sm[i]);
+    }
+    uint64_t mk[1] = {(uint64_t)f32_ord(m) << 32};
+    wave_sort_desc<1>(mk, lane);
+    const uint32_t thi = __shfl((uint32_t)(mk[0] >> 32), K - 1, 64);  // ord(T)
+
+    // candidate strips -> wave-private list (ballot prefix per i)
+    int nstr = 0;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const bool pass = lane + 64 * i < ns && f32_ord(sm[i]) >= thi;
+        const unsigned long long mask = __ballot(pass);
+        const int pos = nstr + __popcll(mask & ((1ull << lane) - 1ull));
+        if (pass && pos < TS_MAX_STRIPS) slist[pos] = lane + 64 * i;
+        nstr += __popcll(mask);
+    }
+    if (nstr > TS_MAX_STRIPS) {
+        topk_row_generic(row, H, K, list, lane, vrow, irow, fallback_rows);
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // read the candidate strips, 16 per pass: lane l -> strip slist[base + l / 4], float4 number l & 3
+    int total = 0;
+    for (int base = 0; base < nstr; base += 16) {
+        const int si = base + (lane >> 2);
+        const bool in = si < nstr;
+        const int s = in ? slist[si] : 0;
+        const int e = s * 16 + (lane & 3) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) v = *(const float4*)(row + e);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t o = f32_ord(vv[c]);
+            const bool pass = in && o >= thi;
+            const unsigned long long mask = __ballot(pass);
+            if (mask) {
+                const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pass && pos < TOPK_CAP) list[pos] = ((uint64_t)o << 32) | (uint32_t)(~(uint32_t)(e + c));
+                total += __popcll(mask);
+            }
+        }
+    }
+    if (total > TOPK_CAP || total < K) {
+        topk_row_generic(row, H, K, list, lane, vrow, irow, fallback_rows);
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (total <= 64)
+        topk_emit<1>(list, total, K, lane, vrow, irow);
+    else if (total <= 128)
+        topk_emit<2>(list, total, K, lane, vrow, irow);
+    else
+        topk_emit<4>(list, total, K, lane, vrow, irow);
+}
+
+// ------------------------------------------------------------------------------------------------
 // select_kernel: final TopK of the fused path.  One wave per row gathers the row's candidates from its
 // per-tile slot groups (lanes over tiles, ballot-free prefix via wave scan), and if they are a
 // complete answer (>= K candidates, no slot group overflowed, <= TOPK_CAP in total) sorts them and
@@ -945,9 +1046,13 @@ static int gemm_dense(wsae_ctx* c, const float* params, int B, int nfeat, int ws
         static int cus = 0;
         if (!cus && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1))
             cus = 256;
+        // strip maxima for the strip-guided TopK kernel when this is the full pre-activation matrix of the ctx
+        float* smax = (pre == c->pre && nfeat == c->H && ldp == c->H) ? c->smax : nullptr;
         encode_gemm256p_kernel<T><<<min(ntiles, cus), 512, 4 * T256_LDS, st>>>((const T*)c->xb, W, bias, pre, ldp, B, nfeat,
-                                                                            c->D, ntn, ntiles);
+                                                                            c->D, ntn, ntiles, smax);
+        if (smax) c->smax_valid = 1;
     } else {
+        if (pre == c->pre) c->smax_valid = 0;
         encode_gemm_kernel<T, GEMM_DENSE><<<gg, 256, 2 * TILE_LDS_BYTES, st>>>(
             (const T*)c->xb, W, bias, pre, ldp, B, nfeat, c->D, wstride, arows, n_dev, nullptr, 0, nullptr, nullptr,
             nullptr);
@@ -1080,7 +1185,14 @@ extern "C" int wsae_encode_topk(wsae_ctx* ctx, const float* params, const void* 
     if (rc) return rc;
     WSAE_PROF_BEGIN(ctx, WSAE_K_TOPK, st);
     const int vpl = ceil_div(ctx->H, 256);
-    if (ctx->K <= 64 && vpl <= 4)
+    static const bool no_strips = getenv("WSAE_TOPK_ROWS") != nullptr;  // A/B runs
+    const int ns = ctx->H / 16;
+    if (ctx->smax_valid && !no_strips && ctx->K <= 64 && ctx->H % 16 == 0 && ns >= 64 && ns <= 512) {
+        if (ns <= 192)
+            topk_strips_kernel<3><<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, ctx->smax, B, ctx->H, ctx->K, vals, idx, step_count, fb);
+        else
+            topk_strips_kernel<8><<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, ctx->smax, B, ctx->H, ctx->K, vals, idx, step_count, fb);
+    } else if (ctx->K <= 64 && vpl <= 4)
         topk_rows_kernel<4><<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb);
     else if (ctx->K <= 64 && vpl <= 12)
         topk_rows_kernel<12><<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb);
