@@ -205,20 +205,56 @@ struct RowSeg {
     }
 };
 
+// Cross-lane exchanges without the LDS pipe (__shfl / __shfl_xor compile to ds_bpermute_b32; this kernel
+// issued 85 of them per row).  gfx950 has VALU forms for every exchange needed here
+// (profiles/tools/lane_ops_probe.hip prints what each delivers):
+//   xor 32 / xor 16 : v_permlane32_swap / v_permlane16_swap on the pair (a, b) give a' + b' =
+//                     (a + a^M) on the lanes with bit M clear and (b + b^M) on the others - exactly one
+//                     butterfly step, no selects;
+//   xor 8           : DPP row_ror:8;   xor 4: DPP row_shl:4 / row_shr:4 by lane parity;
+//   xor 2 / xor 1   : DPP quad_perm.
+// They cost no time by themselves (the kernel is latency bound) but 28 fewer VGPRs (216 -> 188).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+
+template <int M>
+__device__ __forceinline__ float lane_xor(float x, int li) {  // x of lane (l ^ M), M in {1, 2, 4, 8}
+    if constexpr (M == 1) return dpp_mov<0xB1>(x);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) {
+        // both DPP moves run with every lane active, THEN the select: inside a ternary each would run under a
+        // partial EXEC mask, and a DPP source lane that is masked off reads as invalid
+        const float up = dpp_mov<0x104>(x), dn = dpp_mov<0x114>(x);  // row_shl:4 (lane l + 4), row_shr:4 (lane l - 4)
+        return (li & 4) ? dn : up;
+    } else return dpp_mov<0x128>(x);                       // row_ror:8
+}
+
+// one butterfly step on the pair (a, b): lanes with bit M clear get a + a^M, the others b + b^M
+template <int M>
+__device__ __forceinline__ float pair_step(float a, float b, int li) {
+    if constexpr (M == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+        return __int_as_float(r[0]) + __int_as_float(r[1]);
+    } else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(b), false, false);
+        return __int_as_float(r[0]) + __int_as_float(r[1]);
+    } else {
+        const float sa = a + lane_xor<M>(a, li), sb = b + lane_xor<M>(b, li);
+        return (li & M) ? sb : sa;
+    }
+}
+
 template <int KJ, int N, int M>
 __device__ __forceinline__ void bfly(float (&pd)[KJ], int li) {
     if constexpr (M >= 1) {
         if constexpr (N >= 1) {
-            const bool up = (li & M) != 0;
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const float send = up ? pd[i] : pd[i + N];
-                const float keep = up ? pd[i + N] : pd[i];
-                pd[i] = keep + __shfl_xor(send, M, 64);
-            }
+            for (int i = 0; i < N; ++i) pd[i] = pair_step<M>(pd[i], pd[i + N], li);
             bfly<KJ, N / 2, M / 2>(pd, li);
         } else {
-            pd[0] += __shfl_xor(pd[0], M, 64);
+            pd[0] = pair_step<M>(pd[0], pd[0], li);  // plain all-reduce over the remaining masks
             bfly<KJ, 0, M / 2>(pd, li);
         }
     }
@@ -300,12 +336,16 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
         // ---- gathers of this row first, then the requests for the next row ----
-        float vj[KJ];
+        // feature j = 2 jj + half of this row: v_readlane of lanes 2 jj and 2 jj + 1, picked per half-wave
+        auto val_of = [&](int jj) {
+            const float va = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vr_l), 2 * jj));
+            const float vb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vr_l), 2 * jj + 1));
+            return half ? vb : va;
+        };
 #pragma unroll
         for (int jj = 0; jj < KJ; ++jj) {
-            const int j = 2 * jj + half;
-            vj[jj] = __shfl(vr_l, j, 64);
-            const int fj = __shfl(f_l, j, 64);  // lanes >= K carry feature 0, value 0
+            const int fa = __builtin_amdgcn_readlane(f_l, 2 * jj), fb = __builtin_amdgcn_readlane(f_l, 2 * jj + 1);
+            const int fj = half ? fb : fa;  // lanes >= K carry feature 0, value 0
             seg[jj].load(WdT + (int64_t)fj * D, li);
         }
         const bool more = b + b_step < B;
@@ -321,7 +361,8 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
             for (int q = 0; q < EPL / 2; ++q) acc2[q] = f32x2{0.f, 0.f};
 #pragma unroll
             for (int jj = 0; jj < KJ; ++jj) {
-                const f32x2 v2 = {vj[jj], vj[jj]};
+                const float vjj = val_of(jj);
+                const f32x2 v2 = {vjj, vjj};
 #pragma unroll
                 for (int q = 0; q < EPL / 2; ++q) {
                     const uint32_t u = seg[jj].w[q];
@@ -338,7 +379,7 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
 #pragma unroll
             for (int jj = 0; jj < KJ; ++jj) {
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) acc[e] = fmaf(vj[jj], seg[jj].get(e), acc[e]);
+                for (int e = 0; e < EPL; ++e) acc[e] = fmaf(val_of(jj), seg[jj].get(e), acc[e]);
             }
         }
         // ---- residual, loss, g (both halves end up with the full sum) ----
@@ -350,7 +391,7 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
             for (int q = 0; q < Seg::EPC; ++q) {
                 const int e = c * Seg::EPC + q;
                 const int d = (32 * c + li) * Seg::EPC + q;
-                rec[q] = acc[e] + __shfl_xor(acc[e], 32, 64) + bsum_s[d];
+                rec[q] = pair_step<32>(acc[e], acc[e], lane) + bsum_s[d];  // both halves: the sum over all features
                 const float r = rec[q] - xr[e];
                 g[e] = r * scale;
                 if (half == 0) {
@@ -507,7 +548,10 @@ extern "C" int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* 
     WSAE_REQUIRE(!want_bwd || dpre, "wsae_decode_loss: want_bwd needs a dpre buffer");
     WSAE_REQUIRE(!last_activated || step_count, "wsae_decode_loss: last_activated needs step_count");
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = min(ceil_div(B, 4), WSAE_MAX_PARTIALS);
+    // one round of resident blocks (2 per CU at 188 VGPRs): 58 us against 60 us with 1024 blocks at cfg 2.  Forcing
+    // 3 blocks per CU (168 VGPRs, 84 bytes of spill) was slower (74 us); 1 per CU 75 us: the kernel is latency bound
+    // and neither VALU work, LDS-pipe exchanges, gather width / count nor gather prefetch across rows moved it.
+    const int nblk = min(ceil_div(B, 4), 512);
     int rc;
     WSAE_PROF_BEGIN(ctx, WSAE_K_DECODE, st);
     if (x_dtype == WSAE_DT_F32)
