@@ -135,7 +135,8 @@ decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const fl
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) {
                         const int d = lane + 64 * e;
-                        if (d < D) dot = fmaf(g[e], (float)w[d], dot);
+                        // bf16 mode: dh is taken with bf16(g), like decode_fast_kernel's dot2 pass and the oracle's "amp" mode
+                        if (d < D) dot = fmaf(sizeof(TW) == 2 ? (float)(bf16_t)g[e] : g[e], (float)w[d], dot);
                     }
                     dot = wave_sum(dot);
                     if (lane == j) mine = dot;
