@@ -163,7 +163,7 @@ def main() -> None:
             # (r01_v3_pmc_traffic.csv: 2 x FETCH_SIZE + WRITE_SIZE); measured at the default configuration only
             traffic = 100.7e6 if (B == 16384 and args.precision == "bf16") else None
             achieved = flops_per_launch / (ms_w / n_w * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "wgrad_kernel<bf16>", "achieved": achieved,
+            roof = {"bound": "mfma", "kernel": "wgrad2_kernel<bf16>", "achieved": achieved,
                     "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
                     "traffic": traffic, "avg_launch_ms": ms_w / n_w, "launches": n_w,
                     "step_dense_equiv_tflops": value * f_dense / 1e12,

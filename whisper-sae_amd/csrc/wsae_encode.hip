@@ -340,147 +340,6 @@ encode_gemm256_kernel(const T* __restrict__ xb, const T* __restrict__ W, const f
 }
 
 // ------------------------------------------------------------------------------------------------
-// encode_rows_kernel: the same contraction, organised around the rows instead of around output tiles.
-// A workgroup owns 128 batch rows for a whole range of feature tiles: its x tile (all of K, <= 6 slabs
-// = 108 KB of LDS) is staged ONCE, and only W_e streams -- half the L2 traffic of the tile kernel and
-// one barrier per K slab (W slabs: LDS double buffer + two slabs of register prefetch, so a slab is
-// requested two MFMA phases before it is needed).  D <= 384 (the x tile has to fit LDS).
-// ------------------------------------------------------------------------------------------------
-#define ROWS_MAX_KSLABS 6
-
-template <typename T, int MODE, int NK>
-__global__ void __launch_bounds__(256)
-encode_rows_kernel(const T* __restrict__ xb, const T* __restrict__ W, const float* __restrict__ bias,
-                   float* __restrict__ pre, int ldp, int B, int H, int D, int ntile, int tiles_per_wg,
-                   const float* __restrict__ thr, int thr_stride, uint64_t* __restrict__ cand,
-                   int32_t* __restrict__ cand_cnt, int32_t* __restrict__ ovf, int cap) {
-    static_assert(NK % 2 == 0 && NK <= ROWS_MAX_KSLABS, "K slabs per tile: even, so slab parity is static");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KT = Mfma<T>::KT;
-    char* As = smem;                                  // [NK][128][144]
-    char* Ws = smem + NK * TILE_LDS_BYTES;            // [2][128][144]
-    int* cnt_s = (int*)(Ws + 2 * TILE_LDS_BYTES);     // [128]
-    float* thr_s = (float*)(cnt_s + 128);             // [128]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * TILE_M;
-    const int t_begin = blockIdx.y * tiles_per_wg, t_end = min(ntile, t_begin + tiles_per_wg);
-    if (t_begin >= t_end) return;
-    if (tid < 128) {
-        cnt_s[tid] = 0;
-        if (MODE == GEMM_FILTER) thr_s[tid] = (m0 + tid < B) ? thr[(int64_t)(m0 + tid) * thr_stride] : INFINITY;
-    }
-    // ---- the x tile, once ----
-    {
-        SlabRegs<T> ra[NK / 2];
-#pragma unroll
-        for (int k0 = 0; k0 < NK; k0 += NK / 2) {
-#pragma unroll
-            for (int j = 0; j < NK / 2; ++j) slab_load_fast<T>(ra[j], xb, D, m0, B - 1, (k0 + j) * KT, tid);
-#pragma unroll
-            for (int j = 0; j < NK / 2; ++j) slab_store<T>(ra[j], As + (k0 + j) * TILE_LDS_BYTES, tid);
-        }
-    }
-    // ---- W stream: slab (t, kt); even kt -> rb0 / Ws[0], odd kt -> rb1 / Ws[1]; two slabs in flight ----
-    SlabRegs<T> rb0, rb1;
-    slab_load_fast<T>(rb0, W, D, t_begin * TILE_N, H - 1, 0, tid);
-    slab_load_fast<T>(rb1, W, D, t_begin * TILE_N, H - 1, KT, tid);
-    const int col = lane & 31, rq = lane >> 5;
-    for (int t = t_begin; t < t_end; ++t) {
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        // one K slab: registers R (requested two steps ago) -> LDS buffer WB -> MFMA; then re-request.
-        // A macro over the NAMED rb0/rb1 on purpose: selecting a SlabRegs at run time, by ternary or
-        // through a lambda reference put both of them in scratch memory (hipcc 7.2), 5x slower.
-#define ROWS_STEP(KT_, R, WB)                                                                             \
-    {                                                                                                     \
-        slab_store<T>(R, WB, tid);                                                                        \
-        __syncthreads(); /* slab visible; the other buffer's readers are all past their MFMAs */          \
-        const int kn_ = (KT_) + 2;                                                                        \
-        const int tn_ = kn_ < NK ? t : t + 1; /* same tile, or the head of the next one */                \
-        /* past the last tile the request wraps onto the last tile: harmless, never consumed */           \
-        slab_load_fast<T>(R, W, D, min(tn_, ntile - 1) * TILE_N, H - 1, (kn_ % NK) * KT, tid);            \
-        Mfma<T>::slab(As + (KT_) * TILE_LDS_BYTES, WB, wm * 64, wn * 64, lane, acc);                      \
-    }
-        ROWS_STEP(0, rb0, Ws)
-        ROWS_STEP(1, rb1, Ws + TILE_LDS_BYTES)
-        if (NK > 2) {
-            ROWS_STEP(2, rb0, Ws)
-            ROWS_STEP(3, rb1, Ws + TILE_LDS_BYTES)
-        }
-        if (NK > 4) {
-            ROWS_STEP(4, rb0, Ws)
-            ROWS_STEP(5, rb1, Ws + TILE_LDS_BYTES)
-        }
-#undef ROWS_STEP
-        // ---- epilogue of feature tile t ----
-        const int n0 = t * TILE_N;
-        if (MODE == GEMM_DENSE) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int h = n0 + wn * 64 + ni * 32 + col;
-                    if (h >= H) continue;
-                    const float bv = bias[h];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int b = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-                        if (b < B) pre[(int64_t)b * ldp + h] = acc[mi][ni][r] + bv;
-                    }
-                }
-        } else {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                float tv[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 t4 = *(const float4*)(thr_s + wm * 64 + mi * 32 + 8 * q + 4 * rq);
-                    tv[4 * q] = t4.x; tv[4 * q + 1] = t4.y; tv[4 * q + 2] = t4.z; tv[4 * q + 3] = t4.w;
-                }
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int h = n0 + wn * 64 + ni * 32 + col;
-                    const bool hin = h < H;
-                    const float bv = hin ? bias[h] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[mi][ni][r] + bv;
-                        const bool pass = hin && v >= tv[r];
-                        if (__ballot(pass)) {
-                            if (pass) {
-                                const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-                                // one list per (row, feature-range split), appended to across the tiles
-                                // of this workgroup; write-through (sc1) stores so the candidate stream
-                                // does not evict W_e from the XCD's L2
-                                const int slot = atomicAdd(&cnt_s[rl], 1);
-                                if (slot < cap)
-                                    __hip_atomic_store(cand + ((int64_t)(m0 + rl) * gridDim.y + blockIdx.y) * cap + slot,
-                                                       ((uint64_t)f32_ord(v) << 32) | (uint32_t)(~(uint32_t)h),
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (MODE == GEMM_FILTER) {
-        __syncthreads();
-        if (tid < 128 && m0 + tid < B) {
-            const int c = cnt_s[tid];
-            cand_cnt[(int64_t)(m0 + tid) * gridDim.y + blockIdx.y] = min(c, cap);
-            if (c > cap) ovf[m0 + tid] = 1;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // encode_gemm256p_kernel: the DENSE 256 x 256 GEMM as a persistent kernel - one workgroup per CU walks
 // tiles blockIdx.x, + gridDim.x, ...  What the walk buys over one workgroup per tile (768 tiles = three
 // rounds on 256 CUs, each paying its own start-up and drain): the first operand slabs of the NEXT tile are
@@ -1090,7 +949,6 @@ static int encode_topk_fused(wsae_ctx* c, const float* params, int B, float* val
     const T* W = sizeof(T) == 2 ? (const T*)c->We_bf16 : (const T*)(params + c->off[0]);
     const float* bias = sizeof(T) == 2 ? c->c_fold : params + c->off[2];
     const int ntile = ceil_div(H, TILE_N);
-    const int nk = ceil_div(D, Mfma<T>::KT);
     int ngroup = ntile, cap = CAND_SLOTS;  // candidate lists: [row][ngroup][cap]
     WSAE_PROF_BEGIN(c, WSAE_K_ENCODE_FILTER, st);
     if (H % 256 == 0 && D % Mfma<T>::KT == 0 && B >= 2048) {
@@ -1100,22 +958,6 @@ static int encode_topk_fused(wsae_ctx* c, const float* params, int B, float* val
         encode_gemm256_kernel<T, GEMM_FILTER><<<g2, 512, 4 * T256_LDS + 2048, st>>>(
             (const T*)c->xb, W, bias, nullptr, 0, B, H, D, c->thr_vals + (KS - 1), KS, c->cand, c->cand_cnt, c->cand_ovf,
             cap);
-    } else if (getenv("WSAE_ROWS_KERNEL") && nk <= ROWS_MAX_KSLABS && nk % 2 == 0 && D % Mfma<T>::KT == 0) {
-        // row-owner kernel: enough feature-range splits to put a workgroup on every CU
-        const int nrb = ceil_div(B, TILE_M);
-        int nsp = max(1, min(ntile, ceil_div(256, nrb)));
-        const int tpw = ceil_div(ntile, nsp);
-        nsp = ceil_div(ntile, tpw);
-        ngroup = nsp;
-        cap = min(TOPK_CAP, (ntile * CAND_SLOTS) / nsp);  // same total budget per row, fewer and longer lists
-        dim3 gr(nrb, nsp);
-        const size_t sh = (size_t)(nk + 2) * TILE_LDS_BYTES + 1024;
-#define ROWS_ARGS (const T*)c->xb, W, bias, nullptr, 0, B, H, D, ntile, tpw, c->thr_vals + (KS - 1), KS, c->cand, \
-                  c->cand_cnt, c->cand_ovf, cap
-        if (nk == 6) encode_rows_kernel<T, GEMM_FILTER, 6><<<gr, 256, sh, st>>>(ROWS_ARGS);
-        else if (nk == 4) encode_rows_kernel<T, GEMM_FILTER, 4><<<gr, 256, sh, st>>>(ROWS_ARGS);
-        else encode_rows_kernel<T, GEMM_FILTER, 2><<<gr, 256, sh, st>>>(ROWS_ARGS);
-#undef ROWS_ARGS
     } else {
         dim3 gg(ntile, ceil_div(B, TILE_M));
         encode_gemm_kernel<T, GEMM_FILTER><<<gg, 256, 2 * TILE_LDS_BYTES + 512, st>>>(

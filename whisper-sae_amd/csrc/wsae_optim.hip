@@ -19,56 +19,6 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
-// ---- clip + AdamW, one float4 per thread per iteration ------------------------------------------
-// torch.optim.AdamW (single step t): p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g g;
-// denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom.   g is first scaled by
-// grad_scale (1/world after a SUM all-reduce) and by the clip coefficient
-// min(1, max_norm/(||g||+1e-6)) (torch.nn.utils.clip_grad_norm_).
-__global__ void __launch_bounds__(256)
-adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-             int64_t n4, const float* __restrict__ part_sq, int nparts, float part_scale, float max_norm,
-             float grad_scale, float lr_wd,
-             float beta1, float beta2, float eps, float step_size, float bc2_sqrt, wsae_stats* __restrict__ stats) {
-    __shared__ float red[8];
-    __shared__ float coef_s;
-    float a = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 256) a += part_sq[i];
-    const float tot = block_sum(a, red);
-    if (threadIdx.x == 0) {
-        const float nrm = sqrtf(tot) * part_scale;  // partials may be of the unscaled gradients
-        float coef = 1.f;
-        if (max_norm > 0.f) coef = fminf(1.f, max_norm / (nrm + 1e-6f));
-        coef_s = coef * grad_scale;
-        if (blockIdx.x == 0 && stats) {
-            stats->grad_norm = nrm;
-            stats->clip_coef = coef;
-        }
-    }
-    __syncthreads();
-    const float gs = coef_s;
-    const float decay = 1.f - lr_wd;
-    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
-        const float4 gg = ((const float4*)g)[i];
-        float* pa = (float*)&pp; float* ma = (float*)&mm; float* va = (float*)&vv;
-        const float* ga = (const float*)&gg;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float gc = ga[c] * gs;
-            const float mn = ma[c] + (gc - ma[c]) * omb1;
-            const float vn = beta2 * va[c] + omb2 * gc * gc;
-            const float denom = sqrtf(vn) / bc2_sqrt + eps;
-            pa[c] = pa[c] * decay - step_size * (mn / denom);
-            ma[c] = mn;
-            va[c] = vn;
-        }
-        ((float4*)p)[i] = pp;
-        ((float4*)m)[i] = mm;
-        ((float4*)v)[i] = vv;
-    }
-}
-
 // ---- per-feature-row maintenance, one wave per feature row h ---------------------------------------
 //   NORMALIZE: W_dT[h,:] /= max(||W_dT[h,:]||_2, 1e-12)   == F.normalize(decoder.weight, dim=0), column h
 //   SHADOW   : bf16 shadows of W_e[h,:] and W_dT[h,:], folded bias c[h] = b_e[h] - bf16(W_e)[h,:] . b_pre
@@ -189,6 +139,9 @@ struct AdamArgs {
     float max_norm, grad_scale, part_scale, decay, beta1, beta2, eps, step_size, bc2_sqrt;
 };
 
+// torch.optim.AdamW, single step t: p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g g;
+// denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom.   g is first scaled by gs = clip coefficient *
+// grad_scale (1/world under DDP); decay = 1 - lr*wd, step_size = lr/(1-b1^t), bc2_sqrt = sqrt(1-b2^t) come from the host.
 __device__ __forceinline__ float adam1(float p, float g, float& m, float& v, const AdamArgs& a, float gs) {
     const float gc = g * gs;
     m = m + (gc - m) * (1.f - a.beta1);
