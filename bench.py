@@ -75,9 +75,15 @@ def main() -> None:
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel (adds event overhead)")
+    ap.add_argument("--dims", type=int, nargs=3, metavar=("D", "H", "K"), default=None,
+                    help="informational: other SAE dimensions (e.g. 768 12288 64 = BASELINE.json configs[3]); no roofline object")
     ap.add_argument("--relu", action="store_true", help="informational: ReLU+L1 SAE step (row A12) instead of the TopK "
                                                         "headline; no roofline object")
     args = ap.parse_args()
+
+    global D_MODEL, HIDDEN, TOPK
+    if args.dims:
+        D_MODEL, HIDDEN, TOPK = args.dims
 
     import torch
     import torch.distributed as dist
@@ -157,7 +163,7 @@ def main() -> None:
         # roofline of the dominant kernel: the two weight-gradient contractions, [H,B]x[B,D] each
         n_w, ms_w = prof.get("wgrad", (0, 0.0))
         roof = None
-        if n_w:
+        if n_w and not args.dims and not args.relu:
             flops_per_launch = 2 * (2.0 * HIDDEN * D_MODEL * B)
             # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
             # (r01_v3_pmc_traffic.csv: 2 x FETCH_SIZE + WRITE_SIZE); measured at the default configuration only
@@ -169,11 +175,12 @@ def main() -> None:
                     "step_dense_equiv_tflops": value * f_dense / 1e12,
                     "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS}
         out = {
-            "metric": "activations/sec through SAE train step (d=384->3072, " + ("relu+l1)" if args.relu else "k=32)"),
+            "metric": f"activations/sec through SAE train step (d={D_MODEL}->{HIDDEN}, " + ("relu+l1)" if args.relu else f"k={TOPK})"),
             "value": value, "unit": "activations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": ("ReLUSAE 384->3072 (sparsity_weight 0.01) train step, informational" if args.relu else
+            "config": {"workload": (f"ReLUSAE {D_MODEL}->{HIDDEN} (sparsity_weight 0.01) train step, informational" if args.relu else
+                                    f"TopKSAE {D_MODEL}->{HIDDEN} k={TOPK} train step, informational" if args.dims else
                                     "BASELINE.json configs[1]: TopKSAE 384->3072 k=32 train step") + ", synthetic "
                                    "activations resident in the HBM ring buffer" + ("" if world == 1 else
                                    f" (configs[2]: DDP x{world}, RCCL grad all-reduce)"),

@@ -507,16 +507,16 @@ class TestTopKStrips:
         assert (v == v[0]).all() and (i == i[0]).all()  # identical rows, identical answers
         return v[0], i[0], fb
 
-    @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-    def test_stress_rows(self, device, precision):
-        H, K = 3072, 32
+    @pytest.mark.parametrize("precision,H,K", [("fp32", 3072, 32), ("bf16", 3072, 32), ("bf16", 12288, 64),
+                                               ("fp32", 8192, 48)])
+    def test_stress_rows(self, device, precision, H, K):
         rng = synth.normal((H,), 9, 3)
         rows = {
             "random": rng,
             "all_equal": np.full(H, 0.25, np.float32),                                  # every strip qualifies: exact path
             "plateaus": np.repeat(np.arange(H // 512, dtype=np.float32), 512),           # 512 ties at the top
             "one_strip": np.where(np.arange(H) // 16 == 77, 5.0 + np.arange(H) % 16, rng).astype(np.float32),
-            "winners_spread": np.where(np.arange(H) % 96 == 7, 9.0, rng).astype(np.float32),  # 32 winners, 32 strips
+            "winners_spread": np.where(np.arange(H) % (H // K) == 7, 9.0, rng).astype(np.float32),  # K winners, K strips
             "negative": -np.abs(rng) - 1.0,
         }
         for name, row in rows.items():

@@ -710,7 +710,11 @@ __device__ void topk_row_generic(const float* row, int H, int K, uint64_t* list,
 // ------------------------------------------------------------------------------------------------
 #define TS_MAX_STRIPS 128
 
-template <int SPL>  // strip maxima per lane: H / 16 <= 64 * SPL
+// NTOP = strip maxima each lane contributes to the threshold: 1 -> T = K-th largest of 64 (K <= 32 in practice:
+// at K = 64 that would be the smallest lane maximum and nearly every strip would qualify), 2 -> K-th largest of
+// the 128 values "largest and second largest strip maximum of every lane" (distinct strips, so still >= K
+// distinct elements >= T).
+template <int SPL, int NTOP>  // SPL = strip maxima per lane: H / 16 <= 64 * SPL
 __global__ void __launch_bounds__(256)
 topk_strips_kernel(const float* __restrict__ pre, const float* __restrict__ smax, int B, int H, int K,
                    float* __restrict__ vals, int32_t* __restrict__ idx, int64_t* __restrict__ step_count,
@@ -730,16 +734,25 @@ topk_strips_kernel(const float* __restrict__ pre, const float* __restrict__ smax
     int32_t* irow = idx + (int64_t)b * K;
 
     float sm[SPL];
-    float m = -INFINITY;
+    float m = -INFINITY, m2 = -INFINITY;
 #pragma unroll
     for (int i = 0; i < SPL; ++i) {
         const int s = lane + 64 * i;
         sm[i] = s < ns ? srow[s] : -INFINITY;
+        m2 = fmaxf(m2, fminf(m, sm[i]));
         m = fmaxf(m, sm[i]);
     }
-    uint64_t mk[1] = {(uint64_t)f32_ord(m) << 32};
-    wave_sort_desc<1>(mk, lane);
-    const uint32_t thi = __shfl((uint32_t)(mk[0] >> 32), K - 1, 64);  // ord(T)
+    uint32_t thi;  // ord(T)
+    if constexpr (NTOP == 1) {
+        uint64_t mk[1] = {(uint64_t)f32_ord(m) << 32};
+        wave_sort_desc<1>(mk, lane);
+        thi = __shfl((uint32_t)(mk[0] >> 32), K - 1, 64);
+    } else {
+        uint64_t mk[2] = {(uint64_t)f32_ord(m) << 32, (uint64_t)f32_ord(m2) << 32};
+        wave_sort_desc<2>(mk, lane);  // position p of the descending order sits in lane p / 2, slot p % 2
+        const uint32_t lo = __shfl((uint32_t)(mk[0] >> 32), (K - 1) >> 1, 64), hi = __shfl((uint32_t)(mk[1] >> 32), (K - 1) >> 1, 64);
+        thi = ((K - 1) & 1) ? hi : lo;
+    }
 
     // candidate strips -> wave-private list (ballot prefix per i)
     int nstr = 0;
@@ -1029,11 +1042,19 @@ extern "C" int wsae_encode_topk(wsae_ctx* ctx, const float* params, const void* 
     const int vpl = ceil_div(ctx->H, 256);
     static const bool no_strips = getenv("WSAE_TOPK_ROWS") != nullptr;  // A/B runs
     const int ns = ctx->H / 16;
-    if (ctx->smax_valid && !no_strips && ctx->K <= 64 && ctx->H % 16 == 0 && ns >= 64 && ns <= 512) {
-        if (ns <= 192)
-            topk_strips_kernel<3><<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, ctx->smax, B, ctx->H, ctx->K, vals, idx, step_count, fb);
-        else
-            topk_strips_kernel<8><<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, ctx->smax, B, ctx->H, ctx->K, vals, idx, step_count, fb);
+    if (ctx->smax_valid && !no_strips && ctx->K <= 64 && ctx->H % 16 == 0 && ns >= 128 && ns <= 1024) {
+#define TS_ARGS ctx->pre, ctx->smax, B, ctx->H, ctx->K, vals, idx, step_count, fb
+        const dim3 tg(ceil_div(B, 4));
+        if (ctx->K <= 32) {
+            if (ns <= 192) topk_strips_kernel<3, 1><<<tg, 256, 0, st>>>(TS_ARGS);
+            else if (ns <= 512) topk_strips_kernel<8, 1><<<tg, 256, 0, st>>>(TS_ARGS);
+            else topk_strips_kernel<16, 1><<<tg, 256, 0, st>>>(TS_ARGS);
+        } else {
+            if (ns <= 192) topk_strips_kernel<3, 2><<<tg, 256, 0, st>>>(TS_ARGS);
+            else if (ns <= 512) topk_strips_kernel<8, 2><<<tg, 256, 0, st>>>(TS_ARGS);
+            else topk_strips_kernel<16, 2><<<tg, 256, 0, st>>>(TS_ARGS);
+        }
+#undef TS_ARGS
     } else if (ctx->K <= 64 && vpl <= 4)
         topk_rows_kernel<4><<<ceil_div(B, 4), 256, 0, st>>>(ctx->pre, B, ctx->H, ctx->K, vals, idx, step_count, fb);
     else if (ctx->K <= 64 && vpl <= 12)
