@@ -4,6 +4,8 @@
 //
 // One wave per batch row.  A row of W_dT (one decoder column) is D contiguous floats, so the
 // k gathers per row are coalesced; lane l owns elements l, l+64, ... of the row.
+#include <stdlib.h>
+
 #include "wsae_common.h"
 
 // Block epilogue shared by both decode kernels: write this block's partial sums (loss, l0, and the
@@ -554,9 +556,12 @@ static int dispatch_decode(wsae_ctx* c, const TW* WdT, const float* params, cons
                                           last_activated, step_count, nblk, stats, st);                                   \
         return WSAE_OK;                                                                                            \
     }
+    static const bool no_fast = getenv("WSAE_DEC_GENERIC") != nullptr;  // A/B runs: 105 us against 58 us at cfg 2
+    if (!no_fast) {
     FAST_CASE(12, 16)  // 384, k = 32 (whisper-tiny, cfg 1-3)
     FAST_CASE(2, 4)    // 64, k = 8   (the reference's small test shape)
     FAST_CASE(4, 8)    // 128, k = 16
+    }
 #undef FAST_CASE
     const int nch = ceil_div(c->D, 256);  // 4-element chunks per lane
 #define DEC_CASE(N)                                                                                                \
