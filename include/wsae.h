@@ -234,6 +234,8 @@ int wsae_ring_fill_synthetic(wsae_ring* ring, uint64_t seed, int64_t n_rows, voi
  * HIP events recorded on the launch stream (up to max_samples launches, then recording stops).
  * wsae_profile_read synchronises the recorded events and returns launch count and summed
  * duration.  kernel_id -1 = all kernels.  Ids: see wsae_kernel_name(). */
+/* (ids 4, 5 and 7 are retired - their work moved into the decode, bucket and grad-finish launches - and report 0;
+ * id 9 is the fused optimizer tail, id 14 the split-K reduction + bias gradients) */
 #define WSAE_K_STAGE_BATCH 0
 #define WSAE_K_ENCODE_GEMM 1
 #define WSAE_K_TOPK 2

@@ -338,26 +338,41 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
     // before the current row's gathers, so a row costs one exposed L2 round trip (the gathers), not three
     using Seg = RowSeg<TW, EPL>;
     constexpr int NCH = Seg::NB / Seg::CS;  // chunks per lane; a chunk is Seg::EPC consecutive elements
-    auto load_x = [&](int bb, float (&xr)[EPL]) {
+    // the next row of x is requested a phase ahead and kept RAW (packed bf16 when the input is bf16): converting at
+    // load time would put the wait for this load - two dependent round trips when rows[] is used - right behind its issue
+    constexpr int XW = (XDT == WSAE_DT_BF16) ? EPL / 2 : EPL;  // dwords per lane
+    constexpr bool XVEC = Seg::EPC == 4;                        // 8-byte (bf16) / 16-byte (f32) chunk loads
+    auto load_x = [&](int bb, uint32_t (&xw)[XW]) {
         const int64_t src = rows ? (int64_t)rows[bb] : (int64_t)bb;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int64_t o = src * D + (32 * c + li) * Seg::EPC;
-            if (XDT == WSAE_DT_BF16 && Seg::EPC == 4) {
-                const bf16x4 t = *(const bf16x4*)((const bf16_t*)x + o);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) xr[c * 4 + q] = (float)t[q];
-            } else if (XDT == WSAE_DT_F32 && Seg::EPC == 4) {
-                const float4 t = *(const float4*)((const float*)x + o);
-                xr[c * 4] = t.x; xr[c * 4 + 1] = t.y; xr[c * 4 + 2] = t.z; xr[c * 4 + 3] = t.w;
+            if constexpr (XDT == WSAE_DT_BF16 && XVEC) {
+                const uint2 t = *(const uint2*)((const bf16_t*)x + o);
+                xw[2 * c] = t.x; xw[2 * c + 1] = t.y;
+            } else if constexpr (XDT == WSAE_DT_F32 && XVEC) {
+                const uint4 t = *(const uint4*)((const float*)x + o);
+                xw[4 * c] = t.x; xw[4 * c + 1] = t.y; xw[4 * c + 2] = t.z; xw[4 * c + 3] = t.w;
+            } else if constexpr (XDT == WSAE_DT_BF16) {  // EPC == 2: one dword = two bf16
+                static_assert(Seg::EPC == 2 || XVEC, "bf16 rows come in chunks of 2 or 4 elements");
+                xw[c] = *(const uint32_t*)((const bf16_t*)x + o);
             } else {
 #pragma unroll
-                for (int q = 0; q < Seg::EPC; ++q) xr[c * Seg::EPC + q] = load_act<XDT>(x, o + q);
+                for (int q = 0; q < Seg::EPC; ++q) xw[c * Seg::EPC + q] = *(const uint32_t*)((const float*)x + o + q);
             }
         }
     };
+    auto x_at = [&](const uint32_t (&xw)[XW], int e) -> float {  // element e of this lane's share of the row
+        if constexpr (XDT == WSAE_DT_BF16) {
+            const uint32_t u = xw[e >> 1];
+            return __uint_as_float((e & 1) ? (u & 0xFFFF0000u) : (u << 16));
+        } else {
+            return __uint_as_float(xw[e]);
+        }
+    };
     const int b_first = blockIdx.x * 4 + wave, b_step = gridDim.x * 4;
-    float v_n = 0.f, xr[EPL];
+    float v_n = 0.f;
+    uint32_t xr[XW];
     int f_n = 0;
     if (b_first < B) {
         v_n = (lane < K) ? vals[(int64_t)b_first * K + lane] : 0.f;
@@ -437,7 +452,7 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
                 const int e = c * Seg::EPC + q;
                 const int d = (32 * c + li) * Seg::EPC + q;
                 rec[q] = pair_step<32>(acc[e], acc[e], lane) + bsum_s[d];  // both halves: the sum over all features
-                const float r = rec[q] - xr[e];
+                const float r = rec[q] - x_at(xr, e);
                 g[e] = r * scale;
                 if (half == 0) {
                     loss_acc = fmaf(r, r, loss_acc);
@@ -461,11 +476,17 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
         if (more) load_x(b + b_step, xr);  // lands under the dpre pass
         // ---- dpre_j = (v_j > 0) ? g . W_dT[idx_j, :] : 0 ----
         if (BWD) {
-            float pd[KJ];
+            // dot of g with feature row jj of this half (rows stay PACKED across the two passes: without the
+            // asm barrier the compiler carries the 16 x 12 unpacked floats of the decode pass over - 354 registers)
+            bf16x2 gq[(EPL + 1) / 2];
+            if constexpr (sizeof(TW) == 2) {
 #pragma unroll
-            for (int jj = 0; jj < KJ; ++jj) {
-                // keep the rows PACKED across the two passes: without this the compiler carries the
-                // 16 x 12 unpacked floats of the decode pass over (354 registers, 1 wave per SIMD)
+                for (int q = 0; q < EPL / 2; ++q) {
+                    gq[q][0] = (bf16_t)g[2 * q];
+                    gq[q][1] = (bf16_t)g[2 * q + 1];
+                }
+            }
+            auto row_dot = [&](int jj) {
 #pragma unroll
                 for (int q = 0; q < RowSeg<TW, EPL>::NW; ++q) asm volatile("" : "+v"(seg[jj].w[q]));
                 float dot = 0.f;
@@ -473,23 +494,26 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
                     // bf16 rows against bf16(g): v_dot2c_f32_bf16, exact products, fp32 accumulate
 #pragma unroll
                     for (int q = 0; q < EPL / 2; ++q) {
-                        bf16x2 gq;
-                        gq[0] = (bf16_t)g[2 * q];
-                        gq[1] = (bf16_t)g[2 * q + 1];
                         const uint32_t u = seg[jj].w[q];
-                        dot = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2*)&u, gq, dot, false);
+                        dot = __builtin_amdgcn_fdot2_f32_bf16(*(const bf16x2*)&u, gq[q], dot, false);
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) dot = fmaf(g[e], seg[jj].get(e), dot);
                 }
-                pd[jj] = dot;
+                return dot;
+            };
+            // transposing butterfly over the 32 lanes of each half: a stage with lane mask m halves the number of
+            // live values (lanes with the bit set keep the upper half); once one value is left the remaining masks
+            // are a plain all-reduce.  Lane li ends up with the total of jj = top log2(KJ) bits of li.  The first
+            // stage (mask 16, pairs jj / jj + KJ/2) is taken as soon as both dots of a pair exist: KJ/2 live values.
+            float pd[KJ / 2];
+#pragma unroll
+            for (int i = 0; i < KJ / 2; ++i) {
+                const float a = row_dot(i), c2 = row_dot(i + KJ / 2);
+                pd[i] = pair_step<16>(a, c2, li);
             }
-            // transposing butterfly over the 32 lanes of each half: a stage with lane mask m halves
-            // the number of live values (lanes with the bit set keep the upper half); once one value
-            // is left the remaining masks are a plain all-reduce.  Lane li ends up with the total of
-            // jj = top log2(KJ) bits of li.
-            bfly<KJ, KJ / 2, 16>(pd, li);
+            bfly<KJ / 2, KJ / 4, 8>(pd, li);
             // which jj does this lane hold?  the selection bits came from li's top log2(KJ) bits
             int sh = 0;
 #pragma unroll
