@@ -479,20 +479,26 @@ encode_gemm256p_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
 //   path: bisection on the 64-bit key for the K-th largest key, then the same compaction + sort.
 // ------------------------------------------------------------------------------------------------
 // partner key at lane distance stride / NPL (the loops around the call are fully unrolled, so the switch folds)
-template <int NPL>
-__device__ __forceinline__ uint64_t xor_partner(uint64_t k, int stride, int lane) {
+template <int M>
+__device__ __forceinline__ uint64_t lane_xor_key(uint64_t k, int lane) { return lane_xor_u64<M>(k, lane); }
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor_key(uint32_t k, int lane) { return lane_xor_u32<M>(k, lane); }
+
+template <int NPL, typename KT>
+__device__ __forceinline__ KT xor_partner(KT k, int stride, int lane) {
     switch (stride / NPL) {
-        case 1: return lane_xor_u64<1>(k, lane);
-        case 2: return lane_xor_u64<2>(k, lane);
-        case 4: return lane_xor_u64<4>(k, lane);
-        case 8: return lane_xor_u64<8>(k, lane);
-        case 16: return lane_xor_u64<16>(k, lane);
-        default: return lane_xor_u64<32>(k, lane);
+        case 1: return lane_xor_key<1>(k, lane);
+        case 2: return lane_xor_key<2>(k, lane);
+        case 4: return lane_xor_key<4>(k, lane);
+        case 8: return lane_xor_key<8>(k, lane);
+        case 16: return lane_xor_key<16>(k, lane);
+        default: return lane_xor_key<32>(k, lane);
     }
 }
 
-template <int NPL>
-__device__ __forceinline__ void wave_sort_desc(uint64_t (&key)[NPL], int lane) {
+// (KT = uint32_t when only the value decides - the threshold sorts - halves the work of the 64-bit (value, index) keys)
+template <int NPL, typename KT = uint64_t>
+__device__ __forceinline__ void wave_sort_desc(KT (&key)[NPL], int lane) {
 #pragma unroll
     for (int size = 2; size <= 64 * NPL; size <<= 1) {
 #pragma unroll
@@ -500,13 +506,13 @@ __device__ __forceinline__ void wave_sort_desc(uint64_t (&key)[NPL], int lane) {
             if (stride >= NPL) {
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
-                    const uint64_t other = xor_partner<NPL>(key[i], stride, lane);
+                    const KT other = xor_partner<NPL>(key[i], stride, lane);
                     const int p = lane * NPL + i;
                     const bool desc = (p & size) == 0;
                     const bool lower = (p & stride) == 0;
                     const bool keep_max = (lower == desc);
-                    const uint64_t mx = key[i] > other ? key[i] : other;
-                    const uint64_t mn = key[i] > other ? other : key[i];
+                    const KT mx = key[i] > other ? key[i] : other;
+                    const KT mn = key[i] > other ? other : key[i];
                     key[i] = keep_max ? mx : mn;
                 }
             } else {
@@ -516,8 +522,8 @@ __device__ __forceinline__ void wave_sort_desc(uint64_t (&key)[NPL], int lane) {
                         const int j = i | stride;
                         const int p = lane * NPL + i;
                         const bool desc = (p & size) == 0;
-                        const uint64_t a = key[i], b = key[j];
-                        const uint64_t mx = a > b ? a : b, mn = a > b ? b : a;
+                        const KT a = key[i], b = key[j];
+                        const KT mx = a > b ? a : b, mn = a > b ? b : a;
                         key[i] = desc ? mx : mn;
                         key[j] = desc ? mn : mx;
                     }
@@ -678,9 +684,9 @@ topk_rows_kernel(const float* __restrict__ pre, int B, int H, int K, float* __re
         v[i] = e < H ? *(const float4*)(row + e) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         m = fmaxf(fmaxf(m, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
     }
-    uint64_t mk[1] = {(uint64_t)f32_ord(m) << 32};
-    wave_sort_desc<1>(mk, lane);
-    const uint32_t thi = __shfl((uint32_t)(mk[0] >> 32), K - 1, 64);  // ord(T): 64 distinct elements are >= T
+    uint32_t mk[1] = {f32_ord(m)};
+    wave_sort_desc<1, uint32_t>(mk, lane);
+    const uint32_t thi = __shfl(mk[0], K - 1, 64);  // ord(T): 64 distinct elements are >= T
 
     int cnt = 0;
 #pragma unroll
@@ -780,13 +786,13 @@ topk_strips_kernel(const float* __restrict__ pre, const float* __restrict__ smax
     }
     uint32_t thi;  // ord(T)
     if constexpr (NTOP == 1) {
-        uint64_t mk[1] = {(uint64_t)f32_ord(m) << 32};
-        wave_sort_desc<1>(mk, lane);
-        thi = __shfl((uint32_t)(mk[0] >> 32), K - 1, 64);
+        uint32_t mk[1] = {f32_ord(m)};
+        wave_sort_desc<1, uint32_t>(mk, lane);
+        thi = __shfl(mk[0], K - 1, 64);
     } else {
-        uint64_t mk[2] = {(uint64_t)f32_ord(m) << 32, (uint64_t)f32_ord(m2) << 32};
-        wave_sort_desc<2>(mk, lane);  // position p of the descending order sits in lane p / 2, slot p % 2
-        const uint32_t lo = __shfl((uint32_t)(mk[0] >> 32), (K - 1) >> 1, 64), hi = __shfl((uint32_t)(mk[1] >> 32), (K - 1) >> 1, 64);
+        uint32_t mk[2] = {f32_ord(m), f32_ord(m2)};
+        wave_sort_desc<2, uint32_t>(mk, lane);  // position p of the descending order sits in lane p / 2, slot p % 2
+        const uint32_t lo = __shfl(mk[0], (K - 1) >> 1, 64), hi = __shfl(mk[1], (K - 1) >> 1, 64);
         thi = ((K - 1) & 1) ? hi : lo;
     }
 
