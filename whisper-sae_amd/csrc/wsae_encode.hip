@@ -468,6 +468,116 @@ encode_gemm256p_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// encode_gemm256d_kernel: encode_gemm256p_kernel with both operands staged by LDS-DMA into the swizzled,
+// unpadded image (wsae_mfma.h): no staging registers, no ds_write pass, 8 one-KB pieces per wave and K step,
+// issued before the MFMAs of the previous step.  LDS: stage 0 at [0, 64 KB), stage 1 at [72 KB, 136 KB); the
+// epilogue's transpose patches (69.6 KB) take stage 0's place, so the next tile's first slabs can already be
+// landing in stage 1 while the current tile is stored: with an even number of K steps (checked by the launcher)
+// every tile starts in stage 1, ends its MFMAs in stage 0, and finds the next tile's first slab in stage 1.
+// ------------------------------------------------------------------------------------------------
+#define G256D_STAGE (2 * 256 * SWZ_ROW_BYTES)           // A tile + W tile = 64 KB
+#define G256D_STAGE1 (72 * 1024)
+#define G256D_LDS (G256D_STAGE1 + G256D_STAGE)          // 136 KB
+
+template <typename T>
+__global__ void __launch_bounds__(512)
+encode_gemm256d_kernel(const T* __restrict__ xb, const T* __restrict__ W, const float* __restrict__ bias,
+                       float* __restrict__ pre, int ldp, int B, int H, int D, int ntn, int ntiles,
+                       float* __restrict__ smax) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = SWZ_ROW_BYTES / (int)sizeof(T);
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = D / KT;
+    const int col = lane & 31, rq = lane >> 5;
+    constexpr int PS = 68;
+    float* patch = (float*)smem + wave * 32 * PS;  // inside stage 0's region
+    const int pr = lane >> 4, pc = (lane & 15) * 4;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int dma_r = lane >> 3, dma_s = lane & 7;
+
+    const int ntm = ntiles / ntn;
+    const bool xcd_walk = (gridDim.x % 8 == 0) && (ntm % 8 == 0);
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    auto tile_at = [&](int i) -> int {
+        if (!xcd_walk) return (int)blockIdx.x + i * (int)gridDim.x;
+        const int tl = local + i * per_xcd;
+        if (tl >= (ntm >> 3) * ntn) return ntiles;
+        return (xcd * (ntm >> 3) + tl / ntn) * ntn + tl % ntn;
+    };
+    // K slab k0 of tile (m0, n0) into stage st: pieces 0..31 = A rows, 32..63 = W rows; this wave takes 8 of them
+    auto dma = [&](int m0, int n0, int k0, int st) {
+        const uint32_t base = smem_lds + (st ? G256D_STAGE1 : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int piece = wave + 8 * j;            // 0..63
+            const int row = (piece & 31) * 8 + dma_r;  // row inside the 256-row operand tile
+            const int c = dma_s ^ ((row >> 1) & 7);
+            const T* src = piece < 32 ? xb + (int64_t)min(m0 + row, B - 1) * D + k0 + c * EPC
+                                      : W + (int64_t)min(n0 + row, H - 1) * D + k0 + c * EPC;
+            glds16(src, base + piece * 1024);
+        }
+    };
+
+    int it = 0, st = 1;
+    int tile = tile_at(0);
+    if (tile < ntiles) dma((tile / ntn) * 256, (tile % ntn) * 256, 0, st);
+    for (; tile < ntiles; tile = tile_at(++it)) {
+        const int m0 = (tile / ntn) * 256, n0 = (tile % ntn) * 256;
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int nt = min(tile_at(it + 1), ntiles - 1);
+        for (int kt = 0; kt < nk; ++kt) {
+            dma_wait();       // slab kt (issued one step ago) has landed
+            __syncthreads();  // ... for every wave; and everybody is done reading the other stage
+            // request the next slab into the other stage: the next K step of this tile, or the first of the next tile
+            if (kt + 1 < nk) dma(m0, n0, (kt + 1) * KT, st ^ 1);
+            else dma((nt / ntn) * 256, (nt % ntn) * 256, 0, st ^ 1);
+            const char* As = smem + (st ? G256D_STAGE1 : 0);
+            Mfma256s<T>::slab(As, As + 256 * SWZ_ROW_BYTES, wm * 128, wn * 64, lane, acc);
+            st ^= 1;
+        }
+        // the slab in flight targets stage 1 (st == 1 again); the patches take stage 0's place
+        __syncthreads();  // every wave is done reading stage 0
+        const int hcol = n0 + wn * 64 + pc;
+        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hcol < H) bv4 = *(const float4*)(bias + hcol);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * rq) * PS + ni * 32 + col] = acc[mi][ni][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rl = pr + 4 * i;
+                const int b = m0 + wm * 128 + mi * 32 + rl;
+                float4 v = *(const float4*)(patch + rl * PS + pc);
+                v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+                if (b < B && hcol < H) *(float4*)(pre + (int64_t)b * ldp + hcol) = v;
+                if (smax) {
+                    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xF, 0xF, false)));
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xF, 0xF, false)));
+                    if ((lane & 3) == 0 && b < B && hcol < H) smax[(int64_t)b * (H >> 4) + (hcol >> 4)] = m;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // (the loop top's barrier separates these patch reads from the next slab landing in stage 0)
+    }
+    dma_wait();
+}
+
+// ------------------------------------------------------------------------------------------------
 // TopK: one wave per row.
 //   key = (orderable(value) << 32) | ~index : descending key order == (value desc, index asc).
 //   1. per-lane maximum over the lane's share of the row;
@@ -962,6 +1072,11 @@ static int gemm_dense(wsae_ctx* c, const float* params, int B, int nfeat, int ws
             cus = 256;
         // strip maxima for the strip-guided TopK kernel when this is the full pre-activation matrix of the ctx
         float* smax = (pre == c->pre && nfeat == c->H && ldp == c->H) ? c->smax : nullptr;
+        static const bool no_dma = getenv("WSAE_GEMM_REGSTAGE") != nullptr;  // A/B: the register-staged kernel (+6 us at cfg 2)
+        if (!no_dma && (c->D / Mfma<T>::KT) % 2 == 0)
+            encode_gemm256d_kernel<T><<<min(ntiles, cus), 512, G256D_LDS, st>>>((const T*)c->xb, W, bias, pre, ldp, B, nfeat,
+                                                                               c->D, ntn, ntiles, smax);
+        else
         encode_gemm256p_kernel<T><<<min(ntiles, cus), 512, 4 * T256_LDS, st>>>((const T*)c->xb, W, bias, pre, ldp, B, nfeat,
                                                                             c->D, ntn, ntiles, smax);
         if (smax) c->smax_valid = 1;

@@ -217,6 +217,22 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to 1 KB of LDS at the
+// wave-uniform address dst.  Inline asm rather than __builtin_amdgcn_global_load_lds: hipcc orders
+// every LDS access that follows the builtin behind s_waitcnt vmcnt(0), which would land the whole
+// slab before the MFMA phase instead of underneath it.  The asm load is invisible to hipcc's wait
+// counting, so the kernel waits for it explicitly (dma_wait) before the barrier that publishes it.
+// M0 (the DMA's LDS base) is compiler-reserved: saved and restored around the instruction.
+__device__ __forceinline__ void glds16(const void* src, uint32_t lds_byte) {
+    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(lds_byte);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_addr)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // wave tile (32 MI) x 96 = MI x 3 MFMA tiles: MI = 3 is 144 accumulator VGPRs and 6 fragment reads
 // per 9 MFMAs (two waves per SIMD); MI = 2 is 96 VGPRs and 5 reads per 6 MFMAs (three waves per SIMD)
 template <typename T, int MI>
@@ -300,6 +316,62 @@ struct Mfma96<float, MI> {
             const f32x4 a = *(const f32x4*)(As + swz_off(r, k2 * 4 + q));
 #pragma unroll
             for (int j = 0; j < 4; ++j) rs = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], 1.0f, rs, 0, 0, 0);
+        }
+    }
+};
+
+// 256 x 256 workgroup tile on the swizzled image: a wave owns 128 rows x 64 columns = 4 x 2 MFMA tiles (as Mfma256)
+template <typename T>
+struct Mfma256s;
+
+template <>
+struct Mfma256s<bf16_t> {
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
+                                                f32x16 (&acc)[4][2]) {
+        const int r = lane & 31, h = lane >> 5;
+        const int sw = (r >> 1) & 7;
+        const char* ap = As + (a_row0 + r) * SWZ_ROW_BYTES;
+        const char* bp = Bs + (b_row0 + r) * SWZ_ROW_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int co = ((kk * 2 + h) ^ sw) << 4;
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(ap + i * 32 * SWZ_ROW_BYTES + co);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b[i] = *(const bf16x8*)(bp + i * 32 * SWZ_ROW_BYTES + co);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+
+template <>
+struct Mfma256s<float> {
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
+                                                f32x16 (&acc)[4][2]) {
+        const int r = lane & 31, h = lane >> 5;
+        const int sw = (r >> 1) & 7;
+        const char* ap = As + (a_row0 + r) * SWZ_ROW_BYTES;
+        const char* bp = Bs + (b_row0 + r) * SWZ_ROW_BYTES;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {  // same k permutation in both operands (see Mfma96<float>)
+            const int co = ((cc * 2 + h) ^ sw) << 4;
+            f32x4 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *(const f32x4*)(ap + i * 32 * SWZ_ROW_BYTES + co);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b[i] = *(const f32x4*)(bp + i * 32 * SWZ_ROW_BYTES + co);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
         }
     }
 };

@@ -252,22 +252,6 @@ wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid
 // -> barrier.  Every VMEM operation issued at the top of an iteration has the whole MFMA phase to land,
 // so the vmcnt(0) that __syncthreads() implies costs nothing.
 // ------------------------------------------------------------------------------------------------
-// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to 1 KB of LDS at the
-// wave-uniform address dst.  Inline asm rather than __builtin_amdgcn_global_load_lds: hipcc orders
-// every LDS access that follows the builtin behind s_waitcnt vmcnt(0), which would land the whole
-// slab before the MFMA phase instead of underneath it.  The asm load is invisible to hipcc's wait
-// counting, so the kernel waits for it explicitly (dma_wait) before the barrier that publishes it.
-// M0 (the DMA's LDS base) is compiler-reserved: saved and restored around the instruction.
-__device__ __forceinline__ void glds16(const void* src, uint32_t lds_byte) {
-    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(lds_byte);
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(lds_addr)
-                 : "memory");
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 #define W2_M 192
 #define W2_N 384
 #define W2_A_BYTES (W2_M * SWZ_ROW_BYTES)
