@@ -333,10 +333,11 @@ class TestReLUSAE:
                        (m.decoder.bias, "db_d")):
             assert rel(cpu(p.grad), g[key]) < 2e-5, key
 
-    @pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
-    def test_ragged_shapes_against_the_oracle(self, device, precision, tol):
-        """Batch and widths that are not multiples of the 64/128 tiles (B = 200, D = 96, H = 352)."""
-        D, H, B = 96, 352, 200
+    @pytest.mark.parametrize("precision,tol,D,H,B", [("fp32", 2e-5, 96, 352, 200), ("bf16", 2e-2, 96, 352, 200),
+                                                     ("fp32", 2e-5, 384, 3072, 1000), ("bf16", 2e-2, 384, 3072, 1000)])
+    def test_ragged_shapes_against_the_oracle(self, device, precision, tol, D, H, B):
+        """Batches and widths that are not multiples of the 64/128/256 tiles; the larger shape takes the persistent
+        LDS-DMA GEMM (split-K for the two weight-gradient contractions), the smaller one the simple 128 x 128 kernel."""
         m, w = self._build(D, H, 5, True, device, precision, weight=0.05)
         x = synth.activations(B, D, seed=5, stream=2, bf16=True)
         out = m(torch.from_numpy(x).to(device))
@@ -348,9 +349,16 @@ class TestReLUSAE:
         assert abs(float(out.loss.detach()) - float(f["loss"])) / float(f["loss"]) < ftol
         assert abs(float(out.sparsity_loss) - float(f["sparsity_loss"])) / float(f["sparsity_loss"]) < ftol
         assert rel(cpu(out.reconstructed), f["reconstructed"]) < ftol
+        # a pre-activation within summation-order noise of zero may sit on either side of the relu in the two
+        # computations; such a feature's dW_e / db_e row legitimately differs, so those rows are left out
+        sure = (np.abs(f["pre"]) > 1e-6 * np.abs(f["pre"]).max()).all(axis=0)
+        assert sure.mean() > 0.99
         for p, key in ((m.encoder.weight, "W_e"), (m.encoder.bias, "b_e"), (m.decoder.weight, "W_d"),
                        (m.decoder.bias, "b_d")):
-            assert rel(cpu(p.grad), b[key]) < tol, key
+            got, want = cpu(p.grad), b[key]
+            if key in ("W_e", "b_e"):
+                got, want = got[sure], want[sure]
+            assert rel(got, want) < tol, key
 
     def test_trainer_step_matches_autograd_plus_adamw(self, device, tmp_path):
         """SAETrainer drives the ReLU module (the reference's trainer crashes on it): one fused step equals the

@@ -199,3 +199,6 @@ __device__ __forceinline__ float load_act(const void* p, int64_t i) {
 // internal (wsae_encode.hip): stage the batch (xb, xT) and run the dense encoder GEMM into pre [B][H]
 int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,
                                  int B, float* pre, hipStream_t st);
+// internal (wsae_encode.hip): the persistent LDS-DMA NT GEMM for other dense contractions; false = shape not supported
+bool wsae_internal_gemm256d(wsae_ctx* c, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias, float* C,
+                            int64_t ldc, int M, int N, int K, int nsplit, int64_t cz, hipStream_t st);

@@ -479,11 +479,14 @@ encode_gemm256p_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
 #define G256D_STAGE1 (72 * 1024)
 #define G256D_LDS (G256D_STAGE1 + G256D_STAGE)          // 136 KB
 
+// Generic form: C[M][N] (+ z * cz) = A[M][K range z] . Bt[N][K range z]^T (+ bias[n] on z = 0); the encoder GEMM is
+// (A = xb, Bt = W_e, K = D, one K range); the ReLU SAE's dense GEMMs use the split-K form (wsae_relu.hip).
+// B, H, D below are M, N and the K extent of ONE range (kper); lda / ldb / ldp the leading dimensions.
 template <typename T>
 __global__ void __launch_bounds__(512)
-encode_gemm256d_kernel(const T* __restrict__ xb, const T* __restrict__ W, const float* __restrict__ bias,
-                       float* __restrict__ pre, int ldp, int B, int H, int D, int ntn, int ntiles,
-                       float* __restrict__ smax) {
+encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restrict__ W, int64_t ldb,
+                       const float* __restrict__ bias, float* __restrict__ pre, int64_t ldp, int B, int H, int D, int ntn,
+                       int ntiles_mn, int nsplit, int64_t cz, float* __restrict__ smax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = SWZ_ROW_BYTES / (int)sizeof(T);
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -497,8 +500,9 @@ encode_gemm256d_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int dma_r = lane >> 3, dma_s = lane & 7;
 
-    const int ntm = ntiles / ntn;
-    const bool xcd_walk = (gridDim.x % 8 == 0) && (ntm % 8 == 0);
+    const int ntiles = ntiles_mn * nsplit;  // work items: (K range z, tile)
+    const int ntm = ntiles_mn / ntn;
+    const bool xcd_walk = nsplit == 1 && (gridDim.x % 8 == 0) && (ntm % 8 == 0);
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     auto tile_at = [&](int i) -> int {
         if (!xcd_walk) return (int)blockIdx.x + i * (int)gridDim.x;
@@ -506,25 +510,30 @@ encode_gemm256d_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
         if (tl >= (ntm >> 3) * ntn) return ntiles;
         return (xcd * (ntm >> 3) + tl / ntn) * ntn + tl % ntn;
     };
-    // K slab k0 of tile (m0, n0) into stage st: pieces 0..31 = A rows, 32..63 = W rows; this wave takes 8 of them
-    auto dma = [&](int m0, int n0, int k0, int st) {
+    // K slab k0 (absolute element offset) of tile (m0, n0) into stage st: pieces 0..31 = A rows, 32..63 = Bt rows
+    auto dma = [&](int m0, int n0, int64_t k0, int st) {
         const uint32_t base = smem_lds + (st ? G256D_STAGE1 : 0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int piece = wave + 8 * j;            // 0..63
             const int row = (piece & 31) * 8 + dma_r;  // row inside the 256-row operand tile
             const int c = dma_s ^ ((row >> 1) & 7);
-            const T* src = piece < 32 ? xb + (int64_t)min(m0 + row, B - 1) * D + k0 + c * EPC
-                                      : W + (int64_t)min(n0 + row, H - 1) * D + k0 + c * EPC;
+            const T* src = piece < 32 ? xb + (int64_t)min(m0 + row, B - 1) * lda + k0 + c * EPC
+                                      : W + (int64_t)min(n0 + row, H - 1) * ldb + k0 + c * EPC;
             glds16(src, base + piece * 1024);
         }
     };
+    auto m_of = [&](int t) { return ((t % ntiles_mn) / ntn) * 256; };
+    auto n_of = [&](int t) { return ((t % ntiles_mn) % ntn) * 256; };
+    auto k_of = [&](int t) { return (int64_t)(t / ntiles_mn) * D; };  // first element of the tile's K range
 
     int it = 0, st = 1;
     int tile = tile_at(0);
-    if (tile < ntiles) dma((tile / ntn) * 256, (tile % ntn) * 256, 0, st);
+    if (tile < ntiles) dma(m_of(tile), n_of(tile), k_of(tile), st);
     for (; tile < ntiles; tile = tile_at(++it)) {
-        const int m0 = (tile / ntn) * 256, n0 = (tile % ntn) * 256;
+        const int m0 = m_of(tile), n0 = n_of(tile);
+        const int64_t kbase = k_of(tile);
+        const int z = tile / ntiles_mn;
         f32x16 acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -537,8 +546,8 @@ encode_gemm256d_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
             dma_wait();       // slab kt (issued one step ago) has landed
             __syncthreads();  // ... for every wave; and everybody is done reading the other stage
             // request the next slab into the other stage: the next K step of this tile, or the first of the next tile
-            if (kt + 1 < nk) dma(m0, n0, (kt + 1) * KT, st ^ 1);
-            else dma((nt / ntn) * 256, (nt % ntn) * 256, 0, st ^ 1);
+            if (kt + 1 < nk) dma(m0, n0, kbase + (int64_t)(kt + 1) * KT, st ^ 1);
+            else dma(m_of(nt), n_of(nt), k_of(nt), st ^ 1);
             const char* As = smem + (st ? G256D_STAGE1 : 0);
             Mfma256s<T>::slab(As, As + 256 * SWZ_ROW_BYTES, wm * 128, wn * 64, lane, acc);
             st ^= 1;
@@ -547,7 +556,8 @@ encode_gemm256d_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
         __syncthreads();  // every wave is done reading stage 0
         const int hcol = n0 + wn * 64 + pc;
         float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (hcol < H) bv4 = *(const float4*)(bias + hcol);
+        if (bias && z == 0 && hcol < H) bv4 = *(const float4*)(bias + hcol);
+        float* Cz = pre + (int64_t)z * cz;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -562,7 +572,7 @@ encode_gemm256d_kernel(const T* __restrict__ xb, const T* __restrict__ W, const 
                 const int b = m0 + wm * 128 + mi * 32 + rl;
                 float4 v = *(const float4*)(patch + rl * PS + pc);
                 v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
-                if (b < B && hcol < H) *(float4*)(pre + (int64_t)b * ldp + hcol) = v;
+                if (b < B && hcol < H) *(float4*)(Cz + (int64_t)b * ldp + hcol) = v;
                 if (smax) {
                     float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
                     m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xF, 0xF, false)));
@@ -1074,8 +1084,8 @@ static int gemm_dense(wsae_ctx* c, const float* params, int B, int nfeat, int ws
         float* smax = (pre == c->pre && nfeat == c->H && ldp == c->H) ? c->smax : nullptr;
         static const bool no_dma = getenv("WSAE_GEMM_REGSTAGE") != nullptr;  // A/B: the register-staged kernel (+6 us at cfg 2)
         if (!no_dma && (c->D / Mfma<T>::KT) % 2 == 0)
-            encode_gemm256d_kernel<T><<<min(ntiles, cus), 512, G256D_LDS, st>>>((const T*)c->xb, W, bias, pre, ldp, B, nfeat,
-                                                                               c->D, ntn, ntiles, smax);
+            encode_gemm256d_kernel<T><<<min(ntiles, cus), 512, G256D_LDS, st>>>((const T*)c->xb, c->D, W, c->D, bias, pre, ldp, B,
+                                                                               nfeat, c->D, ntn, ntiles, 1, 0, smax);
         else
         encode_gemm256p_kernel<T><<<min(ntiles, cus), 512, 4 * T256_LDS, st>>>((const T*)c->xb, W, bias, pre, ldp, B, nfeat,
                                                                             c->D, ntn, ntiles, smax);
@@ -1157,6 +1167,30 @@ static int check_batch(const wsae_ctx* c, const void* x, int x_dtype, int B, con
     WSAE_REQUIRE(B >= 1 && B <= c->maxB, "%s: batch %d outside [1, max_batch=%d]", who, B, c->maxB);
     WSAE_REQUIRE(x_dtype == WSAE_DT_F32 || x_dtype == WSAE_DT_BF16, "%s: unknown activation dtype %d", who, x_dtype);
     return WSAE_OK;
+}
+
+// Persistent LDS-DMA GEMM for other callers (wsae_relu.hip): C[M][N] (+ z * cz) = A . Bt^T over nsplit K ranges of
+// K / nsplit elements each.  Returns false when the shape does not qualify (caller falls back to its own kernel).
+template <typename T>
+static bool gemm256d_try(wsae_ctx* c, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias, float* C,
+                         int64_t ldc, int M, int N, int K, int nsplit, int64_t cz, hipStream_t st) {
+    constexpr int KT = SWZ_ROW_BYTES / (int)sizeof(T);
+    if (M < 512 || N < 128 || N % 4 || K % nsplit || (K / nsplit) % (2 * KT) || lda % (16 / (int)sizeof(T)) ||
+        ldb % (16 / (int)sizeof(T)) || ldc % 4)
+        return false;
+    static int cus = 0;
+    if (!cus && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1)) cus = 256;
+    const int ntn = ceil_div(N, 256), ntiles_mn = ntn * ceil_div(M, 256);
+    encode_gemm256d_kernel<T><<<min(ntiles_mn * nsplit, cus), 512, G256D_LDS, st>>>((const T*)A, lda, (const T*)Bt, ldb, bias, C, ldc,
+                                                                                   M, N, K / nsplit, ntn, ntiles_mn, nsplit, cz,
+                                                                                   nullptr);
+    return true;
+}
+
+bool wsae_internal_gemm256d(wsae_ctx* c, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias, float* C,
+                            int64_t ldc, int M, int N, int K, int nsplit, int64_t cz, hipStream_t st) {
+    return c->prec == WSAE_PREC_BF16 ? gemm256d_try<bf16_t>(c, A, lda, Bt, ldb, bias, C, ldc, M, N, K, nsplit, cz, st)
+                                     : gemm256d_try<float>(c, A, lda, Bt, ldb, bias, C, ldc, M, N, K, nsplit, cz, st);
 }
 
 int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,

@@ -134,12 +134,23 @@ gemm_nt_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ Bt, i
         }
 }
 
+// nz_out: the number of K ranges actually used (slabs to sum).  Large shapes go to the persistent LDS-DMA GEMM of the
+// encoder (wsae_encode.hip); everything else to the simple 128 x 128 kernel above.
 template <typename T>
-void gemm_nt(hipStream_t st, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias, float* C,
-             int64_t ldc, int M, int N, int K, int nz, int64_t cz) {
+void gemm_nt(wsae_ctx* c, hipStream_t st, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias, float* C,
+             int64_t ldc, int M, int N, int K, int nz, int64_t cz, int* nz_out = nullptr) {
     constexpr int KT = Mfma<T>::KT;
+    for (int ns = nz; ns >= 1; ns >>= 1) {  // largest power-of-two split (<= nz) whose ranges are whole pairs of K slabs
+        if (K % ns || (K / ns) % (2 * KT)) continue;
+        if (wsae_internal_gemm256d(c, A, lda, Bt, ldb, bias, C, ldc, M, N, K, ns, cz, st)) {
+            if (nz_out) *nz_out = ns;
+            return;
+        }
+        break;
+    }
     const int kper = ceil_div(ceil_div(K, nz), KT) * KT;
     dim3 grid(ceil_div(N, TILE_N), ceil_div(M, TILE_M), ceil_div(K, kper));
+    if (nz_out) *nz_out = (int)grid.z;
     gemm_nt_kernel<T><<<grid, 256, 2 * TILE_LDS_BYTES, st>>>((const T*)A, lda, (const T*)Bt, ldb, bias, C, ldc, M, N, K, kper, cz);
 }
 
@@ -370,7 +381,7 @@ int forward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     transpose_w_kernel<T><<<dim3(ceil_div(H, 64), ceil_div(D, 64)), 256, 0, st>>>(wdt, (T*)ws.wd_nt, H, D);
     dim3 ga(ceil_div(H, 64), ceil_div(ldT, 64));
     relu_act_kernel<T><<<ga, 256, 0, st>>>(ctx->pre, hidden, (T*)ws.hid, (T*)ws.hidT, B, H, ldT, ws.part, ws.nblk);
-    gemm_nt<T>(st, ws.hid, H, ws.wd_nt, H, params + ctx->off[3], recon, D, B, D, H, 1, 0);  // recon = hidden W_d^T + b_d
+    gemm_nt<T>(ctx, st, ws.hid, H, ws.wd_nt, H, params + ctx->off[3], recon, D, B, D, H, 1, 0);  // recon = hidden W_d^T + b_d
     dim3 gr(ceil_div(D, 64), ceil_div(ldT, 64));
     if (x_dtype == WSAE_DT_F32)
         resid_kernel<T, WSAE_DT_F32, false><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, 0.f, nullptr, nullptr, nullptr,
@@ -400,16 +411,17 @@ int backward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
         resid_kernel<T, WSAE_DT_BF16, true><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, scale, (T*)ctx->xb, (T*)ctx->gT,
                                                                ctx->part_dbd, ws.part + 2 * ws.nblk);
     const T* wdt = sizeof(T) == 2 ? (const T*)ctx->WdT_bf16 : (const T*)(params + ctx->off[1]);
-    gemm_nt<T>(st, ctx->xb, D, wdt, D, nullptr, ctx->pre, H, B, H, D, 1, 0);  // dh = g W_d  [B][H]
+    gemm_nt<T>(ctx, st, ctx->xb, D, wdt, D, nullptr, ctx->pre, H, B, H, D, 1, 0);  // dh = g W_d  [B][H]
     dim3 ga(ceil_div(H, 64), ceil_div(ldT, 64));
     dpre_kernel<T><<<ga, 256, 0, st>>>(ctx->pre, hidden, B, H, ldT, weight / ((float)B * (float)H), (T*)ws.dpreT, ws.colpart);
     // split-K contractions over the batch into the slabs: [z][ dW_e (H*D) | dW_dT (H*D) ]
     const int nz = min(WSAE_WGRAD_MAX_SPLIT, max(1, ldT / 512));
     const int64_t hd = (int64_t)H * D, slab_stride = 2 * hd;
-    gemm_nt<T>(st, ws.dpreT, ldT, ctx->xT, ldT, nullptr, ctx->wg_slabs, D, H, D, ldT, nz, slab_stride);
-    gemm_nt<T>(st, ws.hidT, ldT, ctx->gT, ldT, nullptr, ctx->wg_slabs + hd, D, H, D, ldT, nz, slab_stride);
-    constexpr int KT = Mfma<T>::KT;
-    const int nz_eff = ceil_div(ldT, ceil_div(ceil_div(ldT, nz), KT) * KT);
+    int nz_e = 1, nz_d = 1;
+    gemm_nt<T>(ctx, st, ws.dpreT, ldT, ctx->xT, ldT, nullptr, ctx->wg_slabs, D, H, D, ldT, nz, slab_stride, &nz_e);
+    gemm_nt<T>(ctx, st, ws.hidT, ldT, ctx->gT, ldT, nullptr, ctx->wg_slabs + hd, D, H, D, ldT, nz, slab_stride, &nz_d);
+    const int nz_eff = nz_e;  // both contractions have the same shape, hence the same split
+    (void)nz_d;
     slab_sum_kernel<<<512, 256, 0, st>>>(ctx->wg_slabs, slab_stride, nz_eff, slab_stride / 4, grads, grads + ctx->off[4], D);
     colsum_kernel<<<ceil_div(H, 256), 256, 0, st>>>(ws.colpart, ceil_div(B, 64), H, grads + ctx->off[2]);
     colsum_kernel<<<ceil_div(D, 256), 256, 0, st>>>(ctx->part_dbd, ceil_div(B, 64), D, grads + ctx->off[3]);
