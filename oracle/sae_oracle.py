@@ -128,6 +128,26 @@ def topk_select(pre: np.ndarray, k: int):
     return vals.astype(F32), order.astype(np.int64)
 
 
+def check_selection(pre: np.ndarray, idx: np.ndarray, k: int, rtol: float = 1e-5) -> np.ndarray:
+    """Per-row verdict: is ``idx`` a valid TopK-k index set of ``pre`` up to a relative slack ``rtol``?
+
+    Valid means: k distinct indices; every element clearly above the k-th largest value is selected;
+    nothing clearly below it is.  "Clearly" = by more than ``rtol * |k-th value|`` (fp32 accumulation
+    of a length-D dot product in a different order moves a value by ~1e-7 relative).
+    """
+    pre64 = pre.astype(F64)
+    B, H = pre64.shape
+    idx = np.asarray(idx, dtype=np.int64)
+    kth = -np.sort(-pre64, axis=1)[:, k - 1]
+    slack = rtol * np.maximum(np.abs(kth), 1e-30)
+    sel = np.zeros((B, H), dtype=bool)
+    np.put_along_axis(sel, idx, True, axis=1)
+    distinct = sel.sum(axis=1) == k
+    must = pre64 > (kth + slack)[:, None]
+    may = pre64 >= (kth - slack)[:, None]
+    return distinct & ~(must & ~sel).any(axis=1) & ~(sel & ~may).any(axis=1)
+
+
 def densify(vals: np.ndarray, idx: np.ndarray, hidden_dim: int) -> np.ndarray:
     """model.py:115-116: ``zeros_like(pre).scatter_(-1, idx, relu(vals))``."""
     hidden = np.zeros((vals.shape[0], hidden_dim), dtype=F32)
@@ -142,11 +162,22 @@ def decode(st: SAEState, hidden: np.ndarray, mode: str = "fp32") -> np.ndarray:
             + st.b_pre.astype(F64)).astype(F32)
 
 
-def forward(st: SAEState, x: np.ndarray, mode: str = "fp32", training: bool = True) -> dict:
-    """model.py:131-166 ``TopKSAE.forward``; updates dead tracking when ``training``."""
+def forward(st: SAEState, x: np.ndarray, mode: str = "fp32", training: bool = True,
+            select: np.ndarray | None = None) -> dict:
+    """model.py:131-166 ``TopKSAE.forward``; updates dead tracking when ``training``.
+
+    ``select`` (tests only): an index array ``[B, k]`` to use in place of ``topk_select``.  Large-batch
+    parity tests pass the device's selection for the few rows whose k-th / (k+1)-th pre-activations
+    are closer than fp32 summation-order noise (after checking with ``check_selection`` that it IS a
+    valid TopK of those rows up to that noise), so that everything downstream compares element-wise.
+    """
     x = np.asarray(x, dtype=F32)
     pre = pre_activation(st, x, mode)
-    vals, idx = topk_select(pre, st.k)
+    if select is None:
+        vals, idx = topk_select(pre, st.k)
+    else:
+        idx = np.asarray(select, dtype=np.int64)
+        vals = np.take_along_axis(pre, idx, axis=1).astype(F32)
     hidden = densify(vals, idx, st.W_e.shape[0])
     recon = decode(st, hidden, mode)
     resid = recon.astype(F64) - x.astype(F64)
@@ -298,14 +329,14 @@ def lr_at(step: int, base_lr: float, warmup_steps_cfg: int, total_steps: int) ->
 
 def train_step(st: SAEState, x: np.ndarray, lr: float, mode: str = "fp32", max_norm: float = 1.0,
                weight_decay: float = 0.0, beta1: float = 0.9, beta2: float = 0.999,
-               eps: float = 1e-8, world_grads: list | None = None) -> dict:
+               eps: float = 1e-8, world_grads: list | None = None, select: np.ndarray | None = None) -> dict:
     """training.py:161-217 ``SAETrainer.train_step`` minus scheduler bookkeeping.
 
     forward (train mode) -> backward -> global-L2 clip -> AdamW -> decoder column renorm.
     ``world_grads``: optional list of gradient dicts from the other data-parallel ranks; they are
     averaged with this rank's before clipping (mean of per-rank mean-gradients).
     """
-    fwd = forward(st, x, mode, training=True)
+    fwd = forward(st, x, mode, training=True, select=select)
     grads = backward(st, x, fwd, mode)
     if world_grads:
         n = len(world_grads) + 1

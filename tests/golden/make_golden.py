@@ -16,6 +16,10 @@ Golden sets (SURVEY.md row C list):
   G1 forward @ cfg2 dims      G2 gradients            G3 one SAETrainer.train_step
   G4 20-step trajectory       G5 LR schedule          G6 dead-feature tracking
   G7 resample_dead_features   G8 ReLUSAE fwd/grads    G9 API bookkeeping (keys, batch forms)
+  G10 seeded initialisation (torch.manual_seed(42) -> TopKSAE / ReLUSAE parameters)
+  G11 FeatureCache interchange: a cache written by the reference's FeatureCache.save (N1)
+
+``python tests/golden/make_golden.py g10 g11`` regenerates only the named sets.
 """
 
 from __future__ import annotations
@@ -271,12 +275,57 @@ def g8_relu():
     )
 
 
+def tensor_digest(a: np.ndarray) -> np.ndarray:
+    """Order-sensitive 64-bit digest of a tensor's exact bit pattern: [sum of words, sum of (i+1)*word] mod 2^64."""
+    u = np.ascontiguousarray(a).view(np.uint32).astype(np.uint64).reshape(-1)
+    with np.errstate(over="ignore"):
+        w = (np.arange(u.size, dtype=np.uint64) + np.uint64(1)) * u
+        return np.array([u.sum(dtype=np.uint64), w.sum(dtype=np.uint64)], dtype=np.uint64)
+
+
+def g10_seeded_init():
+    """scripts/train.py:84-90,:248 seeds torch and then builds the model: the drop-in module must draw the same
+    parameters for the same seed (same construction and RNG order as model.py:38-89 / :266-286)."""
+    out = {"torch_version": np.array(torch.__version__)}
+    for tag, (D, H, K) in {"cfg2": (384, 3072, 32), "small": (64, 256, 8)}.items():
+        torch.manual_seed(42)
+        m = TopKSAE(D, H, k=K)
+        for k_, v in sd_numpy(m).items():
+            if v.dtype == np.float32:
+                out[f"topk.{tag}.{k_}.digest"] = tensor_digest(v)
+                out[f"topk.{tag}.{k_}.head"] = v.reshape(-1)[:64].copy()
+        nxt = torch.rand(4).numpy()  # the RNG position after construction (the module drew exactly as many numbers)
+        out[f"topk.{tag}.next_rand"] = nxt
+        torch.manual_seed(42)
+        r = ReLUSAE(D, H, sparsity_weight=0.01)
+        for k_, v in sd_numpy(r).items():
+            out[f"relu.{tag}.{k_}.digest"] = tensor_digest(v)
+            out[f"relu.{tag}.{k_}.head"] = v.reshape(-1)[:64].copy()
+        out[f"relu.{tag}.next_rand"] = torch.rand(4).numpy()
+    np.savez_compressed(HERE / "g10_seeded_init.npz", **out)
+
+
+def g11_cache_interchange():
+    """A small activation cache written by the REFERENCE's FeatureCache.save (feature_cache.py:136-167): the
+    ``.pt`` tensor file and its ``_meta.json`` sidecar are data in the reference's on-disk format."""
+    from whisper_sae.config import DataConfig, WhisperConfig  # reference
+    from whisper_sae.data.feature_cache import FeatureCache  # reference
+    target = HERE / "g11_cache"
+    target.mkdir(exist_ok=True)
+    feats = torch.from_numpy(synth.activations(96, 384, seed=77, stream=0, bf16=False))
+    fc = FeatureCache(target, WhisperConfig(), DataConfig(cache_dir=Path("cache")))
+    fc.save(feats, "encoder", 0, num_samples=2)
+    meta_path = fc._get_metadata_path("encoder", 0)
+    meta = json.loads(meta_path.read_text())
+    meta["created_at"] = "2026-01-01T00:00:00"  # pinned so that regenerating the fixture is byte-stable
+    meta_path.write_text(json.dumps(meta, indent=2))
+
+
+SETS = {"g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
+        "g10": g10_seeded_init, "g11": g11_cache_interchange}
+
 if __name__ == "__main__":
-    g1_g2_g3()
-    g4_trajectory()
-    g5_lr()
-    g6_dead()
-    g7_resample()
-    g8_relu()
+    for name in (sys.argv[1:] or list(SETS)):
+        SETS[name]()
     for p in sorted(HERE.glob("g*")):
         print(p.name, p.stat().st_size)

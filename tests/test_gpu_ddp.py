@@ -1,0 +1,138 @@
+"""Data-parallel product path on ONE GPU: two fresh child processes share ``cuda:0``, rendezvous over ``gloo``
+(which reduces device tensors through the host) and each runs the product's ``SAETrainer.train_step`` on its half
+of every batch - the same Python and the same kernels the 8-GPU run executes, with RCCL swapped for gloo.
+
+Checked:
+* both ranks end with bit-identical parameters, AdamW moments, ``feature_last_activated`` and ``step_count``
+  (one all-reduce of ``[gradients | fired]``, rank-0 resample batch broadcast, deterministic kernels);
+* they equal the single-process step on the concatenated batch up to the different summation split
+  (mean of two half-batch gradients vs one full-batch gradient), and the step-1 gradient norm equals the oracle's
+  ``train_step(world_grads=...)``;
+* one dead-feature resample event happens inside the run (``resample_dead_every = 2``) and leaves the ranks
+  in lock-step.
+"""
+
+from __future__ import annotations
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sae_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+D, H, K, B, STEPS, LR = 64, 256, 8, 32, 4, 1e-3
+KEYS = ("encoder.weight", "encoder.bias", "decoder.weight", "decoder.bias", "b_pre")
+
+
+def _make(device, run_dir, use_amp):
+    from whisper_sae.config import TrainingConfig
+    from whisper_sae.sae.model import TopKSAE
+    from whisper_sae.sae.training import SAETrainer
+    w = synth.sae_weights(D, H, seed=3, bf16=False, b_pre_scale=0.05)
+    m = TopKSAE(D, H, k=K, dead_feature_threshold=1)
+    sd = m.state_dict()
+    for key in KEYS:
+        sd[key] = torch.from_numpy(w[key])
+    m.load_state_dict(sd)
+    cfg = TrainingConfig(batch_size=B, learning_rate=LR, weight_decay=0.0, epochs=1, warmup_steps=0,
+                         gradient_clip=1.0, use_amp=use_amp, num_workers=0)
+    tr = SAETrainer(m, cfg, device=device, run_dir=run_dir, resample_dead_every=2, resample_batch_size=48,
+                    resample_dead=True)
+    return m, tr, w
+
+
+def _resample_rows(rank):
+    return torch.from_numpy(synth.activations(200, D, seed=3, stream=40 + rank, bf16=False))
+
+
+def _dump(m, tr, mets, path):
+    sd = m.state_dict()
+    out = {k: sd[k].detach().cpu().numpy() for k in sd}
+    out["exp_avg"] = tr.optimizer._m.cpu().numpy()
+    out["exp_avg_sq"] = tr.optimizer._v.cpu().numpy()
+    out["grad_norm"] = np.array([float(x.grad_norm) for x in mets])
+    out["loss"] = np.array([float(x.loss) for x in mets])
+    out["resampled"] = np.int64(tr.num_resampled_total)
+    np.savez(path, **out)
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str, use_amp: bool):
+    import torch.distributed as dist
+    from torch.utils.data import TensorDataset
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        torch.manual_seed(5)
+        m, tr, _ = _make("cuda:0", os.path.join(out_dir, "run"), use_amp)  # every rank is handed the same run_dir
+        tr.set_resample_dataset(TensorDataset(_resample_rows(rank)))       # ... and owns a different shard of rows
+        xs = synth.activations(STEPS * world * B, D, seed=3, stream=8, bf16=False).reshape(STEPS, world * B, D)
+        mets = []
+        for s in range(STEPS):
+            mine = torch.from_numpy(xs[s, rank * B:(rank + 1) * B]).to("cuda:0")
+            mets.append(tr.train_step(mine))
+        tr.save_checkpoint("ddp.pt")  # rank 0 writes, the others wait: no torn file
+        torch.cuda.synchronize()
+        assert os.path.exists(os.path.join(out_dir, "run", "ddp.pt"))
+        _dump(m, tr, mets, os.path.join(out_dir, f"rank{rank}.npz"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("use_amp", [False, True])
+def test_two_ranks_equal_the_single_process_step(device, tmp_path, use_amp):
+    import torch.multiprocessing as mp
+    from torch.utils.data import TensorDataset
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_amp), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for key in r0.files:
+        if key == "loss":  # per-rank batch means (each rank reports its own half)
+            continue
+        assert np.array_equal(r0[key], r1[key]), f"ranks disagree on {key}"
+    assert int(r0["resampled"]) > 0, "the run was meant to include a resample event"
+    # one clock tick per train step + one per resample forward that found dead features (after steps 2 and 4)
+    assert STEPS < int(r0["step_count"]) <= STEPS + 2
+
+    # ---- the same run in one process on the concatenated batches (rank 0's resample rows, as rank 0 draws them) ----
+    torch.manual_seed(5)
+    m, tr, w = _make(device, tmp_path / "single", use_amp)
+    tr.set_resample_dataset(TensorDataset(_resample_rows(0)))
+    xs = synth.activations(STEPS * world * B, D, seed=3, stream=8, bf16=False).reshape(STEPS, world * B, D)
+    mets = [tr.train_step(torch.from_numpy(xs[s]).to(device)) for s in range(STEPS)]
+    _dump(m, tr, mets, tmp_path / "single.npz")
+    one = np.load(tmp_path / "single.npz")
+    assert int(one["resampled"]) == int(r0["resampled"])
+    assert int(one["step_count"]) == int(r0["step_count"])
+    assert np.array_equal(one["feature_last_activated"], r0["feature_last_activated"])
+    tol = 2e-3 if use_amp else 2e-5
+    assert np.allclose(one["grad_norm"], r0["grad_norm"], rtol=tol)
+    assert abs(one["loss"][0] - 0.5 * (r0["loss"][0] + r1["loss"][0])) < 1e-5 * one["loss"][0]
+    for key in KEYS:
+        diff = np.abs(one[key].astype(np.float64) - r0[key].astype(np.float64))
+        # AdamW's early steps move an entry by ~lr * sign(g): entries with |g| at rounding level may go the other way
+        assert np.mean(diff < 0.05 * LR) > 0.995, key
+        assert diff.max() < 2.5 * LR * STEPS, key
+
+    # ---- step 1 against the oracle's own data-parallel restatement ----
+    st = O.SAEState.from_state_dict(w, k=K, dead_feature_threshold=1)
+    mode = "amp" if use_amp else "fp32"
+    other = st.copy()
+    f1 = O.forward(other, xs[0, B:], mode, training=True)
+    g1 = O.backward(other, xs[0, B:], f1, mode)
+    r = O.train_step(st, xs[0, :B], LR, mode, max_norm=1.0, world_grads=[g1])
+    assert abs(r0["grad_norm"][0] - r["grad_norm"]) / r["grad_norm"] < tol
+    assert abs(r0["loss"][0] - r["loss"]) / r["loss"] < 1e-5

@@ -45,6 +45,13 @@ def merge_clock(last_activated: torch.Tensor, fired_sum: torch.Tensor, step: int
     return torch.where(fired_sum > 0, torch.full_like(last_activated, step), last_activated)
 
 
+def barrier() -> None:
+    """All ranks meet (no-op outside torch.distributed)."""
+    dist, _ = world()
+    if dist is not None:
+        dist.barrier()
+
+
 def rank_and_world() -> tuple:
     dist, n = world()
     return (dist.get_rank(), n) if dist is not None else (0, 1)

@@ -39,11 +39,11 @@ class SAEEngine:
         self.P, self.off = N.pack_layout(self.D, self.H)
         self.lib = N.lib()  # raises WsaeError when the extension is not built
         self.pack = torch.zeros(self.P, dtype=torch.float32, device=self.device)
+        self.generation = 0  # bumped by every call that leaves a batch's staged operands (xT / g / gT) in a ctx
         self._ctx: dict[int, tuple[int, int]] = {}  # precision -> (handle, max_batch)
         self._fresh: dict[int, bool] = {}  # precision -> derived shadows match the pack
         self.stats = torch.zeros(N.STATS_WORDS, dtype=torch.int32, device=self.device)
         self._work: dict = {}
-        self.generation = 0  # bumped by every forward that leaves g / xT / gT in the ctx
 
     # -- pack views ----------------------------------------------------------------------------
     def view(self, name: str, base: torch.Tensor | None = None) -> torch.Tensor:
@@ -80,6 +80,7 @@ class SAEEngine:
             N.check(self.lib.wsae_ctx_create(cfg, handle), "wsae_ctx_create")
         self._ctx[precision] = (handle.value, cap)
         self._fresh[precision] = False
+        self.generation += 1  # a new ctx holds nobody's staged batch
         return handle.value
 
     def invalidate(self) -> None:

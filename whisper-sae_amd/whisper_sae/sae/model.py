@@ -73,6 +73,7 @@ class _TopKForward(torch.autograd.Function):
         step_ptr = module.step_count.data_ptr() if training else 0
         last_ptr = module.feature_last_activated.data_ptr() if training else 0
         pk, xd = eng.pack.data_ptr(), _dtype_code(x2)
+        N.check(lib.wsae_ctx_set_fired(handle, 0), "wsae_ctx_set_fired")  # the trainer's DDP clock exchange is per step
         N.check(lib.wsae_encode_topk(handle, pk, x2.data_ptr(), xd, 0, B, vals.data_ptr(), idx.data_ptr(),
                                      step_ptr, eng.stats.data_ptr(), st), "wsae_encode_topk")
         N.check(lib.wsae_decode_loss(handle, pk, x2.data_ptr(), xd, 0, vals.data_ptr(), idx.data_ptr(), B,
@@ -219,6 +220,7 @@ class TopKSAE(nn.Module):
         N.check(eng.lib.wsae_encode_topk(handle, eng.pack.data_ptr(), x2.data_ptr(), _dtype_code(x2), 0, B,
                                          vals.data_ptr(), idx.data_ptr(), 0, eng.stats.data_ptr(), eng.stream()),
                 "wsae_encode_topk")
+        eng.generation += 1  # the ctx now holds THIS batch's staged operands: an earlier forward must restage
         return eng, handle, x2, vals, idx
 
     @torch.no_grad()
@@ -239,6 +241,7 @@ class TopKSAE(nn.Module):
         pre = torch.empty(B, eng.H, dtype=torch.float32, device=eng.device)
         N.check(eng.lib.wsae_encode_dense(handle, eng.pack.data_ptr(), x2.data_ptr(), _dtype_code(x2), 0, B,
                                           pre.data_ptr(), eng.stream()), "wsae_encode_dense")
+        eng.generation += 1
         return pre.reshape(*x.shape[:-1], eng.H)
 
     @torch.no_grad()
@@ -306,6 +309,9 @@ class TopKSAE(nn.Module):
         if int(eng.stats[5].item()) == 0:  # host decision, as in the reference (model.py:219-220)
             return 0
         training = self.training
+        # (data parallel: this forward runs identically on every rank, so its clock stamps need no exchange - keep
+        # them out of the indicator buffer that rides on the next gradient all-reduce)
+        N.check(lib.wsae_ctx_set_fired(handle, 0), "wsae_ctx_set_fired")
         vals = torch.empty(Br, eng.k, dtype=torch.float32, device=eng.device)
         idx = torch.empty(Br, eng.k, dtype=torch.int32, device=eng.device)
         recon = torch.empty(Br, eng.D, dtype=torch.float32, device=eng.device)
@@ -319,6 +325,7 @@ class TopKSAE(nn.Module):
                                      self.step_count.data_ptr() if training else 0, eng.stats.data_ptr(), st),
                 "wsae_decode_loss")
         row_err = torch.empty(Br, dtype=torch.float32, device=eng.device)
+        eng.generation += 1
         N.check(lib.wsae_row_errors(handle, x2.data_ptr(), xd, 0, recon.data_ptr(), Br, row_err.data_ptr(), st),
                 "wsae_row_errors")
         n_out = torch.zeros(1, dtype=torch.int32, device=eng.device)

@@ -31,7 +31,7 @@ from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
 
 from .. import _native as N
 from ..config import TrainingConfig
-from ..distributed import sync_gradients, world
+from ..distributed import barrier, rank_and_world, sync_gradients, world
 from .engine import _dtype_code, require_device_tensor
 from .optim import FusedAdamW
 
@@ -159,15 +159,30 @@ class SAETrainer:
             return 0
         if self.global_step == 0 or self.global_step % self.resample_dead_every != 0:
             return 0
-        n = len(ds)
-        take = torch.randperm(n)[: self.resample_batch_size]
-        tensors = getattr(ds, "tensors", None)
-        if tensors is not None:  # TensorDataset: one indexed gather instead of per-item __getitem__
-            batch = tensors[0][take]
-        else:
-            items = [ds[int(i)] for i in take]
-            batch = torch.stack([it[0] if isinstance(it, (tuple, list)) else it for it in items])
-        count = self.model.resample_dead_features(batch.to(self.device))
+        dist, nranks = world()
+        batch = None
+        if dist is None or dist.get_rank() == 0:
+            n = len(ds)
+            take = torch.randperm(n)[: self.resample_batch_size]
+            tensors = getattr(ds, "tensors", None)
+            if tensors is not None:  # TensorDataset: one indexed gather instead of per-item __getitem__
+                batch = tensors[0][take.to(tensors[0].device)]
+            else:
+                items = [ds[int(i)] for i in take]
+                batch = torch.stack([it[0] if isinstance(it, (tuple, list)) else it for it in items])
+            batch = batch.to(self.device).float().contiguous()
+        if dist is not None:
+            # data parallel: parameters are replicated, so every rank must apply the IDENTICAL rewrite.  Each rank
+            # holds a different shard of rows; rank 0 draws the resample batch and everybody receives it (rare:
+            # every resample_dead_every steps, <= resample_batch_size x D floats).
+            shape = torch.zeros(2, dtype=torch.int64, device=self.device)
+            if batch is not None:
+                shape[0], shape[1] = batch.shape[0], batch.shape[1]
+            dist.broadcast(shape, src=0)
+            if batch is None:
+                batch = torch.empty(int(shape[0]), int(shape[1]), dtype=torch.float32, device=self.device)
+            dist.broadcast(batch, src=0)
+        count = self.model.resample_dead_features(batch)
         self.num_resampled_total += count
         if count > 0 and self.wandb_run is not None:
             self.wandb_run.log({"train/features_resampled": count}, step=self.global_step)
@@ -295,7 +310,8 @@ class SAETrainer:
         self.setup_scheduler(steps_per_epoch * epochs)
         columns = (SpinnerColumn(), TextColumn("[progress.description]{task.description}"), BarColumn(),
                    TaskProgressColumn())
-        with Progress(*columns) as progress:
+        # data parallel: every rank runs the loop, rank 0 alone draws the bars and (save_checkpoint) writes files
+        with Progress(*columns, disable=rank_and_world()[0] != 0) as progress:
             outer = progress.add_task(f"[cyan]Training {epochs} epochs", total=epochs)
             for e in range(1, epochs + 1):
                 inner = progress.add_task(f"[green]Epoch {e}/{epochs}", total=steps_per_epoch)
@@ -312,7 +328,12 @@ class SAETrainer:
 
     # -- persistence (reference training.py:318-379: same keys, same file formats) --------------------
     def save_checkpoint(self, filename: str) -> Path:
+        """Under torch.distributed only rank 0 writes (parameters and optimizer state are replicated, and every
+        rank is handed the same ``run_dir``); the others wait at a barrier so that nobody reads a torn file."""
         target = self.run_dir / filename
+        if rank_and_world()[0] != 0:
+            barrier()
+            return target
         payload = {
             "model_state_dict": {k: v.detach().clone() for k, v in self.model.state_dict().items()},
             "optimizer_state_dict": self.optimizer.state_dict(),
@@ -321,7 +342,10 @@ class SAETrainer:
             "epoch": self.epoch,
             "config": self.config.model_dump(),
         }
-        torch.save(payload, target)
+        tmp = target.with_name(target.name + ".tmp")
+        torch.save(payload, tmp)
+        tmp.replace(target)  # atomic on POSIX: a reader sees the old file or the new one
+        barrier()
         return target
 
     def load_checkpoint(self, path) -> None:
@@ -335,6 +359,8 @@ class SAETrainer:
 
     def save_metrics(self, filename: str = "metrics.json") -> Path:
         target = self.run_dir / filename
+        if rank_and_world()[0] != 0:  # rank 0's history is the run's history (metrics are per-rank batch means)
+            return target
         keys = ("step", "loss", "reconstruction_loss", "sparsity_loss", "l0", "dead_feature_ratio", "learning_rate")
         rows = [{k: getattr(m, k) for k in keys} for m in self.metrics_history]
         target.write_text(json.dumps(rows, indent=2))
