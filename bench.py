@@ -138,7 +138,7 @@ def main() -> None:
     handle = eng.ctx(prec, B)
     # events around the dominant kernel only (two event records per step) inside the timed region
     dominant = N.lib().wsae_kernel_name  # noqa: F841
-    kid = -1 if args.profile_all else 6  # WSAE_K_WGRAD
+    kid = -1 if args.profile_all else N.K_WGRAD
     N.check(N.lib().wsae_profile_enable(handle, kid, args.steps), "wsae_profile_enable")
 
     barrier()

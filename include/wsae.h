@@ -91,13 +91,6 @@ int wsae_param_offsets(int32_t input_dim, int32_t hidden_dim, int64_t offsets[5]
 /* ctx: dims + mode + all workspace (bf16 weight shadows, TopK scratch, partial-sum slabs). */
 int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out);
 int wsae_ctx_destroy(wsae_ctx* ctx);
-/* TopK strategy of wsae_encode_topk.  0 (default): dense pre-activation GEMM + standalone TopK kernel.
- * 1: fused filter path where the shape qualifies (H >= 1024, k <= 64, B >= 512): a sample pass over every
- * 8th feature gives a per-row threshold, the GEMM epilogue keeps only candidates above it, and rows the
- * filter cannot settle are recomputed exactly -- the [B,H] matrix never reaches HBM.  Same results either
- * way; on MI355X at 384->3072/B=16384 the dense path is currently the faster one. */
-int wsae_ctx_set_fused_topk(wsae_ctx* ctx, int32_t on);
-
 /* Data-parallel dead-feature clock without a second collective.  `fired` = float[hidden_dim], zero
  * before the first step, or NULL to switch the mechanism off (the default).  When set:
  *   - wsae_decode_loss stores 1.0f to fired[f] for every feature f it stamps in last_activated
@@ -111,6 +104,9 @@ int wsae_ctx_set_fused_topk(wsae_ctx* ctx, int32_t on);
  * under DDP (the reference itself is single-process). */
 int wsae_ctx_set_fired(wsae_ctx* ctx, float* fired);
 size_t wsae_ctx_workspace_bytes(const wsae_ctx* ctx);
+/* Allocate the dense workspace of the ReLU SAE path (3 x max_batch x hidden_dim operand copies) on the ctx's
+ * device.  Call once after wsae_ctx_create, before the first wsae_relu_forward: launch functions never allocate. */
+int wsae_ctx_reserve_relu(wsae_ctx* ctx);
 
 /* Refresh what the kernels derive from the master weights: bf16 shadow of W_e and the folded
  * encoder bias c[h] = b_e[h] - bf16(W_e)[h,:] . b_pre (BF16 mode).  Must be called after any
@@ -145,7 +141,9 @@ int wsae_decode_dense(wsae_ctx* ctx, const float* params, const float* hidden, i
 /* Sparse decode + MSE + (optionally) the first half of backward, one pass over the compact code
  * (model.py:129,145,148,168-181 and the autograd of them):
  *   recon = sum_j relu(v_j) W_dT[idx_j,:] + b_d + b_pre ; loss = mean((recon-x)^2) ; l0
- *   want_bwd: g = 2 (recon-x)/(B*D) kept in ctx workspace, dpre[b,j] = (v_j>0) ? g . W_dT[idx_j,:] : 0
+ *   want_bwd bit 0: g = 2 (recon-x)/(B*D) kept in ctx workspace (in the contraction dtype),
+ *            dpre[b,j] = (v_j>0) ? g . W_dT[idx_j,:] : 0;   bit 1 (value 2, with bit 0): also keep the fp32 g that
+ *            wsae_input_grad reads (only the autograd API path needs dL/dx)
  *   last_activated (nullable, device int64[H]) with step_count (device int64): features with
  *   v_j > 0 get last_activated = *step_count.
  * recon (nullable): [B,D] f32.  dpre (required when want_bwd): [B,k] f32.
@@ -155,10 +153,17 @@ int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* x, int32_t 
                      float* recon, int32_t want_bwd, float* dpre, int64_t* last_activated,
                      const int64_t* step_count, wsae_stats* stats, void* stream);
 
+/* TopKSAE.forward in one call (model.py:131-166) = wsae_encode_topk followed by wsae_decode_loss on the same batch:
+ * same arguments, same outputs (vals / idx are OUTPUTS here), same record. */
+int wsae_encode_decode(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,
+                       int32_t B, float* vals, int32_t* idx, int64_t* step_count, float* recon, int32_t want_bwd,
+                       float* dpre, int64_t* last_activated, wsae_stats* stats, void* stream);
+
 /* Second half of backward (autograd of model.py:111,129 w.r.t. the parameters): the two
  * [H,B]x[B,D] contractions on MFMA with the sparse operand rebuilt in LDS from the compact code,
  * plus the three bias gradients.  Needs the g left in ctx by wsae_decode_loss(want_bwd=1) on the
- * same batch.  grads: flat pack, overwritten. */
+ * same batch, and the SAME x / x_dtype / rows as that forward (a bf16 batch in BF16 mode is not staged by the
+ * forward: this call transposes it for the dW_e contraction).  grads: flat pack, overwritten. */
 int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                       const int32_t* rows, const float* vals, const int32_t* idx,
                       const float* dpre, int32_t B, float* grads, void* stream);
@@ -234,27 +239,19 @@ int wsae_ring_fill_synthetic(wsae_ring* ring, uint64_t seed, int64_t n_rows, voi
  * HIP events recorded on the launch stream (up to max_samples launches, then recording stops).
  * wsae_profile_read synchronises the recorded events and returns launch count and summed
  * duration.  kernel_id -1 = all kernels.  Ids: see wsae_kernel_name(). */
-/* (ids 4, 5 and 7 are retired - their work moved into the decode, bucket and grad-finish launches - and report 0;
- * id 9 is the fused optimizer tail, id 14 the split-K reduction + bias gradients) */
 #define WSAE_K_STAGE_BATCH 0
 #define WSAE_K_ENCODE_GEMM 1
-#define WSAE_K_TOPK 2
-#define WSAE_K_DECODE 3
-#define WSAE_K_DECODE_FINALIZE 4
-#define WSAE_K_TRANSPOSE_G 5
-#define WSAE_K_WGRAD 6
-#define WSAE_K_BIAS_GRADS 7
-#define WSAE_K_SQNORM 8
-#define WSAE_K_ADAMW 9
-#define WSAE_K_ROWNORM 10
-#define WSAE_K_PREPARE 11
-#define WSAE_K_DEAD_SCAN 12
-#define WSAE_K_MEMSET 13
-#define WSAE_K_WGRAD_REDUCE 14
-#define WSAE_K_BUCKET 15
-#define WSAE_K_ENCODE_FILTER 16
-#define WSAE_K_SELECT 17
-#define WSAE_K_COUNT 18
+#define WSAE_K_TOPK 2          /* standalone TopK launch (absent from the fused training forward) */
+#define WSAE_K_DECODE 3        /* decode + loss + dpre (+ the fused TopK) */
+#define WSAE_K_BUCKET 4        /* counting sort of the compact code + g transposition */
+#define WSAE_K_WGRAD 5         /* the two weight-gradient contractions */
+#define WSAE_K_WGRAD_REDUCE 6  /* split-K reduction + bias gradients */
+#define WSAE_K_SQNORM 7
+#define WSAE_K_ADAMW 8         /* fused optimizer tail */
+#define WSAE_K_ROWNORM 9
+#define WSAE_K_PREPARE 10
+#define WSAE_K_DEAD_SCAN 11
+#define WSAE_K_COUNT 12
 const char* wsae_kernel_name(int32_t kernel_id);
 int wsae_profile_enable(wsae_ctx* ctx, int32_t kernel_id, int32_t max_samples);
 int wsae_profile_disable(wsae_ctx* ctx);
@@ -267,8 +264,7 @@ int wsae_profile_read(wsae_ctx* ctx, int32_t kernel_id, int32_t* n_launches, dou
  * stats->l0 (:313), stats->reserved = the float bits of mean|hidden|; *sparsity_loss_out likewise (may be
  * NULL, as may stats).  backward (must follow the forward of the same batch on the same ctx: it reuses the
  * staged x^T and hidden^T): grads in pack layout, dW_e, dW_dT, db_e, db_d as autograd of model.py:304-311
- * gives them, the b_pre slot set to 0; no dL/dx (the reference has none either).  The first forward on a
- * ctx allocates the dense workspace (3 x B x H operand copies) with hipMalloc; later calls allocate nothing. */
+ * gives them, the b_pre slot set to 0; no dL/dx (the reference has none either).  Needs wsae_ctx_reserve_relu. */
 int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                       const int32_t* rows, int32_t B, float sparsity_weight, float* hidden,
                       float* recon, wsae_stats* stats, float* sparsity_loss_out, void* stream);

@@ -660,61 +660,3 @@ class TestEndToEnd:
         sd = torch.load(run / "sae_final.pt", weights_only=True)
         assert sd["decoder.weight"].shape == (384, 3072) and sd["feature_last_activated"].dtype == torch.int64
         assert int(sd["step_count"]) == 141
-
-
-class TestFusedTopK:
-    """The filter path (sample threshold -> filtering GEMM -> select -> exact fallback) against
-    torch.topk on the kernel's own dense pre-activations, including inputs that defeat the sample."""
-
-    @staticmethod
-    def _fused(m, batch):
-        """Opt this model's bf16 ctx into the fused filter path (the default is dense GEMM + TopK)."""
-        from whisper_sae import _native as N
-        eng = m.bind()
-        N.check(N.lib().wsae_ctx_set_fused_topk(eng.ctx(N.PREC_BF16, batch), 1), "wsae_ctx_set_fused_topk")
-
-    def _model(self, device, bias=None):
-        from whisper_sae.sae.model import TopKSAE
-        torch.manual_seed(3)
-        m = TopKSAE(384, 3072, k=32, precision="bf16").to(device)
-        if bias is not None:
-            with torch.no_grad():
-                m.encoder.bias.copy_(bias.to(device))
-        return m
-
-    def _check(self, m, x):
-        pre = m.pre_activation(x)
-        self._fused(m, x.shape[0])
-        vals, idx = m.encode_compact(x)
-        tv, ti = torch.topk(pre, 32, dim=-1)
-        assert torch.equal(vals, tv)
-        assert torch.equal(torch.sort(idx.long(), dim=1).values, torch.sort(ti, dim=1).values)
-        return int(m._engine.stats[6].item())
-
-    def test_random_rows_use_the_filter(self, device):
-        m = self._model(device)
-        x = torch.from_numpy(synth.activations(2048, 384, seed=5, stream=0)).to(device)
-        before = int(m._engine.stats[6].item()) if m._engine is not None else 0
-        fb = self._check(m, x)
-        assert fb - before < 2048 // 20  # the sample threshold settles (almost) every row
-
-    def test_sample_defeated_rows_fall_back_exactly(self, device):
-        # every 8th feature (= the sample) gets a large bias: the sampled threshold is then far above
-        # the other features, fewer than k candidates survive, and every row must take the fallback
-        bias = torch.zeros(3072)
-        bias[::8] = 50.0
-        m = self._model(device, bias)
-        x = torch.from_numpy(synth.activations(1024, 384, seed=6, stream=0)).to(device)
-        fb = self._check(m, x)
-        assert fb >= 1024
-
-    def test_constant_rows_overflow_the_slots(self, device):
-        m = self._model(device)
-        with torch.no_grad():
-            m.encoder.weight.zero_()  # all pre-activations equal the bias: ties everywhere
-            m.encoder.bias.fill_(0.25)
-        x = torch.from_numpy(synth.activations(512, 384, seed=7, stream=0)).to(device)
-        self._fused(m, 512)
-        vals, idx = m.encode_compact(x)
-        assert torch.all(vals == 0.25)
-        assert torch.equal(idx.long(), torch.arange(32, device=device).expand(512, 32))  # lowest indices win ties

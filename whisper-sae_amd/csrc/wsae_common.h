@@ -67,6 +67,7 @@ struct wsae_prof {
 struct wsae_ctx {
     wsae_prof prof;
     int D, H, K, maxB, prec, device;
+    int cus;              // compute units of `device` (persistent-kernel grid size)
     int64_t P;            // flat pack element count
     int64_t off[5];       // W_e, W_dT, b_e, b_d, b_pre
     // ---- derived shadows -------------------------------------------------------------------
@@ -77,7 +78,11 @@ struct wsae_ctx {
     void* xb;             // [maxB][D] staged batch in compute dtype (bf16 | f32 = x - b_pre)
     void* xT;             // [D][maxB] its transpose (B operand of the dW_e contraction)
     void* gT;             // [D][maxB] g = 2(recon-x)/(BD) transposed, compute dtype
-    float* g;             // [maxB][D] fp32 g (dx path, db_d)
+    float* g;             // [maxB][D] fp32 g (dx path; the contraction operand in FP32 mode)
+    bf16_t* gb;           // [maxB][D] bf16 g (BF16 mode: what the dW_d contraction and dh are fed)
+    int g_is_bf16;        // 1 when the last decode launch left its g in gb (bucket transposes from there)
+    int xT_valid;         // 1 when stage_batch left xT for this batch; 0: wsae_weight_grads transposes x itself
+    int g32_valid;        // 1 when the last decode launch (also) left the fp32 g that wsae_input_grad reads
     float* pre;           // [maxB][H] pre-activation scratch (TopK input)
     float* smax;          // [maxB][H/16] maxima of the 16-column strips of pre (written by the persistent GEMM)
     int smax_valid;       // 1 when smax matches the pre the last dense GEMM wrote
@@ -96,16 +101,8 @@ struct wsae_ctx {
     int32_t* counters;    // small int scratch (fallback rows, resample cursors; [16..) = arrival tickets, 8-byte aligned)
     int32_t* dead_list;   // [H] compacted dead feature indices (resample)
     int32_t* row_order;   // [maxB] rows sorted by error (resample)
-    // ---- fused TopK (filter path) ---------------------------------------------------------------
-    float* thr_vals;      // [maxB][64] sample-pass TopK values (the last one is the row threshold)
-    int32_t* thr_idx;     // [maxB][64]
-    uint64_t* cand;       // [maxB][ceil(H/128)][CAND_SLOTS] candidate keys
-    int32_t* cand_cnt;    // [maxB][ceil(H/128)]
-    int32_t* cand_ovf;    // [maxB] slot-group overflow flags
-    int32_t* flag_rows;   // [maxB] rows sent to the exact fallback
-    void* relu_ws;        // ReLU-SAE workspace (wsae_relu.hip), allocated by the first wsae_relu_forward
+    void* relu_ws;        // ReLU-SAE workspace (wsae_relu.hip), allocated by wsae_ctx_reserve_relu
     float* fired;         // caller-owned [H] indicator buffer for the DDP dead-feature clock, or null
-    int fused_topk;       // 1: filter path (sample threshold + filtering GEMM) instead of dense GEMM + TopK
     int n_dec_blocks;     // blocks used by the last decode launch (partials to reduce)
     int n_sq_parts;       // global-norm partials left in part_sq by the last wsae_weight_grads
     float* dbd2;          // [64][D] level-1 reduction of part_dbd
@@ -198,7 +195,16 @@ __device__ __forceinline__ float load_act(const void* p, int64_t i) {
 
 // internal (wsae_encode.hip): stage the batch (xb, xT) and run the dense encoder GEMM into pre [B][H]
 int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,
-                                 int B, float* pre, hipStream_t st);
+                                 int B, float* pre, int64_t* step_count, int direct, hipStream_t st);
+// internal (wsae_encode.hip): the standalone TopK launch over ctx->pre; whether the strip-guided form applies
+int wsae_internal_topk(wsae_ctx* ctx, int B, float* vals, int32_t* idx, int32_t* fb, hipStream_t st);
+bool wsae_internal_strips_ok(const wsae_ctx* ctx);
+// internal (wsae_decode_mfma.hip): the MFMA decode kernel (BF16 mode)
+bool wsae_internal_decode_mfma_ok(const wsae_ctx* c);
+int wsae_internal_decode_mfma(wsae_ctx* c, const float* params, const void* x, int x_dtype, const int32_t* rows,
+                              const float* vals, const int32_t* idx, int B, float* recon, int want_bwd, float* dpre,
+                              int want_g32, int64_t* last_activated, const int64_t* step_count, wsae_stats* stats,
+                              hipStream_t st);
 // internal (wsae_encode.hip): the persistent LDS-DMA NT GEMM for other dense contractions; false = shape not supported
 bool wsae_internal_gemm256d(wsae_ctx* c, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias, float* C,
                             int64_t ldc, int M, int N, int K, int nsplit, int64_t cz, hipStream_t st);

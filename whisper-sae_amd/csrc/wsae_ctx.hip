@@ -35,6 +35,20 @@ extern "C" int wsae_param_offsets(int32_t D, int32_t H, int64_t off[5]) {
 }
 
 namespace {
+// switch to `device` for the lifetime of the object, then back to whatever was current
+struct DeviceGuard {
+    int prev = -1;
+    bool good = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        good = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    bool ok() const { return good; }
+};
+
 struct Carver {
     size_t total = 0;
     size_t take(size_t bytes) {
@@ -54,7 +68,11 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     WSAE_REQUIRE(maxB >= 1, "max_batch must be >= 1, got %d", maxB);
     WSAE_REQUIRE(cfg->precision == WSAE_PREC_BF16 || cfg->precision == WSAE_PREC_FP32, "unknown precision %d",
                  cfg->precision);
-    WSAE_HIP_CHECK(hipSetDevice(cfg->device));
+    DeviceGuard guard(cfg->device);  // the caller's current device is restored on every return path
+    if (!guard.ok()) {
+        wsae_set_error("hipSetDevice(%d) failed", cfg->device);
+        return WSAE_ERR_HIP;
+    }
 
     wsae_ctx* c = new (std::nothrow) wsae_ctx();
     if (!c) {
@@ -63,6 +81,8 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     }
     memset(c, 0, sizeof(*c));
     c->D = D; c->H = H; c->K = K; c->maxB = maxB; c->prec = cfg->precision; c->device = cfg->device;
+    if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || c->cus < 1)
+        c->cus = 256;
     c->P = wsae_param_count(D, H);
     wsae_param_offsets(D, H, c->off);
 
@@ -76,6 +96,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     const size_t o_xT = cv.take(maxBp * D * esz);
     const size_t o_gT = cv.take(maxBp * D * esz);
     const size_t o_g = cv.take((size_t)maxB * D * 4);
+    const size_t o_gb = cv.take((size_t)maxB * D * 2);
     const size_t o_pre = cv.take((size_t)maxB * H * 4);
     const size_t o_sm = cv.take((size_t)maxB * ((H + 15) / 16) * 4);
     const size_t o_pl = cv.take(WSAE_MAX_PARTIALS * 4);
@@ -92,13 +113,6 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     const size_t o_eh = cv.take((size_t)maxB * K * 4);
     const size_t o_ed = cv.take((size_t)maxB * K * 4);
     const size_t o_eo = cv.take((size_t)((maxB + 31) / 32) * ((H + 127) / 128 + 1) * 4);
-    const size_t ntile = (size_t)(H + 127) / 128;
-    const size_t o_tv = cv.take((size_t)maxB * 64 * 4);
-    const size_t o_ti = cv.take((size_t)maxB * 64 * 4);
-    const size_t o_cd = cv.take((size_t)maxB * ntile * 24 * 8);
-    const size_t o_cc = cv.take((size_t)maxB * ntile * 4);
-    const size_t o_co = cv.take((size_t)maxB * 4);
-    const size_t o_fr = cv.take((size_t)maxB * 4);
     const size_t o_dl = cv.take((size_t)H * 4);
     const size_t o_ro = cv.take((size_t)maxB * 4);
     char* base = nullptr;
@@ -122,6 +136,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     c->xT = base + o_xT;
     c->gT = base + o_gT;
     c->g = (float*)(base + o_g);
+    c->gb = (bf16_t*)(base + o_gb);
     c->pre = (float*)(base + o_pre);
     c->smax = (float*)(base + o_sm);
     c->part_loss = (float*)(base + o_pl);
@@ -138,16 +153,9 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     c->ent_hid = base + o_eh;
     c->ent_dpre = base + o_ed;
     c->ent_off = (int32_t*)(base + o_eo);
-    c->thr_vals = (float*)(base + o_tv);
-    c->thr_idx = (int32_t*)(base + o_ti);
-    c->cand = (uint64_t*)(base + o_cd);
-    c->cand_cnt = (int32_t*)(base + o_cc);
-    c->cand_ovf = (int32_t*)(base + o_co);
-    c->flag_rows = (int32_t*)(base + o_fr);
     c->dead_list = (int32_t*)(base + o_dl);
     c->row_order = (int32_t*)(base + o_ro);
     c->ws_bytes = cv.total;
-    if (const char* e = getenv("WSAE_FUSED_TOPK")) c->fused_topk = atoi(e);  // experiments
     *out = c;
     return WSAE_OK;
 }
@@ -162,9 +170,8 @@ extern "C" int wsae_ctx_destroy(wsae_ctx* ctx) {
 }
 
 // ---- kernel timing -------------------------------------------------------------------------------
-static const char* const k_names[WSAE_K_COUNT] = {
-    "stage_batch", "encode_gemm", "topk", "decode", "decode_finalize", "transpose_g", "wgrad",
-    "bias_grads", "sqnorm", "adamw", "rownorm", "prepare", "dead_scan", "memset", "wgrad_reduce", "bucket", "encode_filter", "select"};
+static const char* const k_names[WSAE_K_COUNT] = {"stage_batch", "encode_gemm", "topk", "decode", "bucket", "wgrad",
+                                                  "wgrad_reduce", "sqnorm", "adamw", "rownorm", "prepare", "dead_scan"};
 
 extern "C" const char* wsae_kernel_name(int32_t id) { return (id >= 0 && id < WSAE_K_COUNT) ? k_names[id] : "?"; }
 
@@ -227,12 +234,6 @@ extern "C" int wsae_profile_read(wsae_ctx* ctx, int32_t kernel_id, int32_t* n_la
 extern "C" int wsae_ctx_set_fired(wsae_ctx* ctx, float* fired) {
     WSAE_REQUIRE(ctx, "wsae_ctx_set_fired: null ctx");
     ctx->fired = fired;
-    return WSAE_OK;
-}
-
-extern "C" int wsae_ctx_set_fused_topk(wsae_ctx* ctx, int32_t on) {
-    WSAE_REQUIRE(ctx, "wsae_ctx_set_fused_topk: null ctx");
-    ctx->fused_topk = on ? 1 : 0;
     return WSAE_OK;
 }
 

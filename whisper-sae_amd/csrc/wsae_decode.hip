@@ -4,52 +4,8 @@
 //
 // One wave per batch row.  A row of W_dT (one decoder column) is D contiguous floats, so the
 // k gathers per row are coalesced; lane l owns elements l, l+64, ... of the row.
-#include <stdlib.h>
-
 #include "wsae_common.h"
-
-// Block epilogue shared by both decode kernels: write this block's partial sums (loss, l0, and the
-// [D] column sums of g) and let the LAST block to arrive reduce the loss / l0 partials in fixed order
-// into the stats record.  Hand-off form (cdna guide, Guideline 16 / microarch "valid forms"): the
-// 4-byte partials are agent-scope atomic (sc1, write-through) stores, drained with vmcnt(0) before
-// the ticket add, and read back with agent-scope atomic loads -- no fences, no separate launch.
-// The [D] column sums are consumed by a later kernel, so plain stores do for them.
-template <bool BWD>
-__device__ __forceinline__ void decode_block_epilogue(float loss_acc, int l0_acc, const float* dbd_s, int D, int B,
-                                                      float* red, float* part_loss, float* part_l0, float* part_dbd,
-                                                      int32_t* ticket, wsae_stats* stats) {
-    const int lane = threadIdx.x & 63;
-    const float bl = block_sum(loss_acc, red);
-    const float b0 = block_sum(lane == 0 ? (float)l0_acc : 0.f, red);
-    if (threadIdx.x == 0) {  // write-through (sc1) stores: visible to the last arriver without a release fence
-        __hip_atomic_store(part_loss + blockIdx.x, bl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(part_l0 + blockIdx.x, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (BWD) {
-        for (int d = threadIdx.x; d < D; d += 256)
-            part_dbd[(int64_t)blockIdx.x * D + d] = dbd_s[d] + dbd_s[D + d] + dbd_s[2 * D + d] + dbd_s[3 * D + d];
-    }
-    __shared__ int last_s;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned unused;
-        last_s = grid_ticket((unsigned long long*)ticket, 0u, &unused);
-    }
-    __syncthreads();
-    if (!last_s) return;
-    float a = 0.f, c = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
-        a += __hip_atomic_load(part_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c += __hip_atomic_load(part_l0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const float ta = block_sum(a, red);
-    const float tc = block_sum(c, red);
-    if (threadIdx.x == 0) {
-        stats->loss = ta / ((float)B * (float)D);
-        stats->l0 = tc / (float)B;
-    }
-}
+#include "wsae_decode_epilogue.h"
 
 // Generic shapes (any D <= 2048 multiple of 4, any K <= 128): lane l owns the 4-element chunks
 // (l + 64 c) * 4 .. + 3, c < NCH, of a row (8- or 16-byte loads, 512 / 1024 contiguous bytes per wave
@@ -200,7 +156,8 @@ decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const fl
             if (dok[c]) *(float4*)(dbd_s + wave * D + dcol[c]) = dbd[c];
         __syncthreads();
     }
-    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, part_loss, part_l0, part_dbd, ticket, stats);
+    __shared__ int last_flag;
+    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, &last_flag, part_loss, part_l0, part_dbd, ticket, stats);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -529,7 +486,8 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
     }
 
     __syncthreads();
-    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, part_loss, part_l0, part_dbd, ticket, stats);
+    __shared__ int last_flag;
+    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, &last_flag, part_loss, part_l0, part_dbd, ticket, stats);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -580,12 +538,9 @@ static int dispatch_decode(wsae_ctx* c, const TW* WdT, const float* params, cons
                                           last_activated, step_count, nblk, stats, st);                                   \
         return WSAE_OK;                                                                                            \
     }
-    static const bool no_fast = getenv("WSAE_DEC_GENERIC") != nullptr;  // A/B runs: 105 us against 58 us at cfg 2
-    if (!no_fast) {
     FAST_CASE(12, 16)  // 384, k = 32 (whisper-tiny, cfg 1-3)
     FAST_CASE(2, 4)    // 64, k = 8   (the reference's small test shape)
     FAST_CASE(4, 8)    // 128, k = 16
-    }
 #undef FAST_CASE
     const int nch = ceil_div(c->D, 256);  // 4-element chunks per lane
 #define DEC_CASE(N)                                                                                                \
@@ -611,37 +566,68 @@ static int dispatch_decode_prec(wsae_ctx* c, const float* params, const void* x,
                                        last_activated, step_count, nblk, stats, st);
 }
 
-extern "C" int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
-                                const int32_t* rows, const float* vals, const int32_t* idx, int32_t B, float* recon,
-                                int32_t want_bwd, float* dpre, int64_t* last_activated, const int64_t* step_count,
-                                wsae_stats* stats, void* stream) {
-    WSAE_REQUIRE(ctx && params && x && vals && idx && stats, "wsae_decode_loss: null argument");
-    WSAE_REQUIRE(B >= 1 && B <= ctx->maxB, "wsae_decode_loss: batch %d outside [1, %d]", B, ctx->maxB);
-    WSAE_REQUIRE(!want_bwd || dpre, "wsae_decode_loss: want_bwd needs a dpre buffer");
-    WSAE_REQUIRE(!last_activated || step_count, "wsae_decode_loss: last_activated needs step_count");
-    hipStream_t st = (hipStream_t)stream;
-    // one round of resident blocks (2 per CU at 188 VGPRs): 58 us against 60 us with 1024 blocks at cfg 2.  Forcing
-    // 3 blocks per CU (168 VGPRs, 84 bytes of spill) was slower (74 us); 1 per CU 75 us: the kernel is latency bound
-    // and neither VALU work, LDS-pipe exchanges, gather width / count nor gather prefetch across rows moved it.
-    const int nblk = min(ceil_div(B, 4), 512);
+static int decode_launch(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,
+                         float* vals, int32_t* idx, int32_t B, float* recon, int32_t want_bwd, float* dpre,
+                         int64_t* last_activated, const int64_t* step_count, wsae_stats* stats, hipStream_t st) {
+    const int bwd = want_bwd & 1, want_g32 = (want_bwd >> 1) & 1;
+    if (wsae_internal_decode_mfma_ok(ctx))
+        return wsae_internal_decode_mfma(ctx, params, x, x_dtype, rows, vals, idx, B, recon, bwd, dpre, want_g32,
+                                         last_activated, step_count, stats, st);
+    // other shapes, FP32 mode: one round of resident blocks of the VALU kernels (2 per CU)
+    const int nblk = min(ceil_div(B, 4), 2 * ctx->cus);
     int rc;
     WSAE_PROF_BEGIN(ctx, WSAE_K_DECODE, st);
     if (x_dtype == WSAE_DT_F32)
-        rc = dispatch_decode_prec<WSAE_DT_F32>(ctx, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,
-                                          step_count, nblk, stats, st);
-    else if (x_dtype == WSAE_DT_BF16)
-        rc = dispatch_decode_prec<WSAE_DT_BF16>(ctx, params, x, rows, vals, idx, B, recon, want_bwd, dpre, last_activated,
-                                           step_count, nblk, stats, st);
-    else {
-        wsae_set_error("wsae_decode_loss: unknown activation dtype %d", x_dtype);
-        return WSAE_ERR_INVALID;
-    }
+        rc = dispatch_decode_prec<WSAE_DT_F32>(ctx, params, x, rows, vals, idx, B, recon, bwd, dpre, last_activated,
+                                               step_count, nblk, stats, st);
+    else
+        rc = dispatch_decode_prec<WSAE_DT_BF16>(ctx, params, x, rows, vals, idx, B, recon, bwd, dpre, last_activated,
+                                                step_count, nblk, stats, st);
     if (rc) return rc;
     WSAE_PROF_END(ctx, WSAE_K_DECODE, st);
     WSAE_LAUNCH_CHECK();
     ctx->n_dec_blocks = nblk;
-    // (g stays row-major in ctx->g; wsae_weight_grads transposes it in its bucket launch)
+    ctx->g_is_bf16 = 0;  // these kernels leave the fp32 g (wsae_weight_grads transposes it in its bucket launch)
+    ctx->g32_valid = bwd;
     return WSAE_OK;
+}
+
+static int check_decode_args(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const float* vals,
+                             const int32_t* idx, int32_t B, int32_t want_bwd, float* dpre, int64_t* last_activated,
+                             const int64_t* step_count, wsae_stats* stats, const char* who) {
+    WSAE_REQUIRE(ctx && params && x && vals && idx && stats, "%s: null argument", who);
+    WSAE_REQUIRE(B >= 1 && B <= ctx->maxB, "%s: batch %d outside [1, %d]", who, B, ctx->maxB);
+    WSAE_REQUIRE(x_dtype == WSAE_DT_F32 || x_dtype == WSAE_DT_BF16, "%s: unknown activation dtype %d", who, x_dtype);
+    WSAE_REQUIRE(!(want_bwd & 1) || dpre, "%s: want_bwd needs a dpre buffer", who);
+    WSAE_REQUIRE(!last_activated || step_count, "%s: last_activated needs step_count", who);
+    return WSAE_OK;
+}
+
+extern "C" int wsae_decode_loss(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                                const int32_t* rows, const float* vals, const int32_t* idx, int32_t B, float* recon,
+                                int32_t want_bwd, float* dpre, int64_t* last_activated, const int64_t* step_count,
+                                wsae_stats* stats, void* stream) {
+    int rc = check_decode_args(ctx, params, x, x_dtype, vals, idx, B, want_bwd, dpre, last_activated, step_count, stats,
+                               "wsae_decode_loss");
+    if (rc) return rc;
+    return decode_launch(ctx, params, x, x_dtype, rows, (float*)vals, (int32_t*)idx, B, recon, want_bwd, dpre, last_activated,
+                         step_count, stats, (hipStream_t)stream);
+}
+
+extern "C" int wsae_encode_decode(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                                  const int32_t* rows, int32_t B, float* vals, int32_t* idx, int64_t* step_count,
+                                  float* recon, int32_t want_bwd, float* dpre, int64_t* last_activated, wsae_stats* stats,
+                                  void* stream) {
+    int rc = check_decode_args(ctx, params, x, x_dtype, vals, idx, B, want_bwd, dpre, last_activated, step_count, stats,
+                               "wsae_encode_decode");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    rc = wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, step_count, 1, st);
+    if (rc) return rc;
+    rc = wsae_internal_topk(ctx, B, vals, idx, &stats->topk_fallback_rows, st);
+    if (rc) return rc;
+    return decode_launch(ctx, params, x, x_dtype, rows, vals, idx, B, recon, want_bwd, dpre, last_activated, step_count, stats,
+                         st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,6 +652,7 @@ __global__ void __launch_bounds__(256) input_grad_kernel(const float* __restrict
 extern "C" int wsae_input_grad(wsae_ctx* ctx, const float* params, const int32_t* idx, const float* dpre, int32_t B,
                                float* dx, void* stream) {
     WSAE_REQUIRE(ctx && params && idx && dpre && dx && B >= 1 && B <= ctx->maxB, "wsae_input_grad: bad argument");
+    WSAE_REQUIRE(ctx->g32_valid, "wsae_input_grad: the preceding decode did not keep the fp32 g (pass want_bwd = 3)");
     input_grad_kernel<<<ceil_div(B, 4), 256, 0, (hipStream_t)stream>>>(params + ctx->off[0], ctx->g, idx, dpre, B, ctx->D,
                                                                        ctx->K, dx);
     WSAE_LAUNCH_CHECK();

@@ -27,8 +27,18 @@ struct ReluWs {
     int nblk;
 };
 
-int ensure_ws(wsae_ctx* c) {
+int reserve_ws(wsae_ctx* c) {
     if (c->relu_ws) return WSAE_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    struct Restore {
+        int d;
+        ~Restore() { if (d >= 0) (void)hipSetDevice(d); }
+    } restore{prev};
+    if (hipSetDevice(c->device) != hipSuccess) {
+        wsae_set_error("wsae_ctx_reserve_relu: hipSetDevice(%d) failed", c->device);
+        return WSAE_ERR_HIP;
+    }
     const size_t es = c->prec == WSAE_PREC_BF16 ? 2 : 4;
     const size_t ldT = ((size_t)c->maxB + 127) / 128 * 128;
     const size_t H = c->H, D = c->D, nb = (ldT + 63) / 64;
@@ -375,7 +385,7 @@ int forward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     const int D = ctx->D, H = ctx->H;
     const int ldT = (B + 127) / 128 * 128;
     const ReluWs ws = host_ws(ctx);
-    int rc = wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, st);  // pre = x W_e^T + b_e
+    int rc = wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, nullptr, 0, st);  // pre = x W_e^T + b_e
     if (rc) return rc;
     const T* wdt = sizeof(T) == 2 ? (const T*)ctx->WdT_bf16 : (const T*)(params + ctx->off[1]);
     transpose_w_kernel<T><<<dim3(ceil_div(H, 64), ceil_div(D, 64)), 256, 0, st>>>(wdt, (T*)ws.wd_nt, H, D);
@@ -432,6 +442,11 @@ int backward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
 
 }  // namespace
 
+extern "C" int wsae_ctx_reserve_relu(wsae_ctx* ctx) {
+    WSAE_REQUIRE(ctx, "wsae_ctx_reserve_relu: null ctx");
+    return reserve_ws(ctx);
+}
+
 extern "C" int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,
                                  int32_t B, float sparsity_weight, float* hidden, float* recon, wsae_stats* stats,
                                  float* sparsity_loss_out, void* stream) {
@@ -439,8 +454,7 @@ extern "C" int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void*
     WSAE_REQUIRE(x_dtype == WSAE_DT_F32 || x_dtype == WSAE_DT_BF16, "wsae_relu_forward: unknown activation dtype %d", x_dtype);
     int rc = check_dims(ctx, B, "wsae_relu_forward");
     if (rc) return rc;
-    rc = ensure_ws(ctx);
-    if (rc) return rc;
+    WSAE_REQUIRE(ctx->relu_ws, "wsae_relu_forward: call wsae_ctx_reserve_relu(ctx) once after wsae_ctx_create");
     hipStream_t st = (hipStream_t)stream;
     return ctx->prec == WSAE_PREC_BF16
                ? forward_t<bf16_t>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, stats, sparsity_loss_out, st)

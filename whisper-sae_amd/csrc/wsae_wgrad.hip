@@ -17,8 +17,6 @@
 // that range's xT/gT columns and compact code (2048 rows at cfg2 = 3.6 MB): each XCD streams its
 // share of the batch from HBM once and the 144 tiles re-read it from L2.  Every split writes a
 // private fp32 slab; a second kernel sums the slabs in fixed order (deterministic, no float atomics).
-#include <stdlib.h>
-
 #include "wsae_common.h"
 #include "wsae_mfma.h"
 
@@ -36,22 +34,44 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 bucket_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, const float* __restrict__ dpre, int B,
               int K, int ntiles, int tw, uint32_t* __restrict__ ent_pos, T* __restrict__ ent_hid, T* __restrict__ ent_dpre,
-              int32_t* __restrict__ ent_off, int nchunks, const float* __restrict__ g, T* __restrict__ gT, int D, int ldT) {
+              int32_t* __restrict__ ent_off, int nchunks, const float* __restrict__ g, const bf16_t* __restrict__ gb,
+              T* __restrict__ gT, int D, int ldT, const bf16_t* __restrict__ xsrc, const int32_t* __restrict__ xrows,
+              T* __restrict__ xT) {
     __shared__ __attribute__((aligned(16))) char sm[64 * 65 * 4];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= nchunks) {
-        // ---- second kind of block: g [B][D] f32 -> gT [D][ldT] in the contraction dtype, zero-padded
-        // beyond column B.  64 x 64 tiles through LDS; 16-byte reads along d, 8/16-byte writes along b.
+        // ---- second kind of block: g [B][D] (f32, or the bf16 copy the MFMA decode kernel leaves: gb != null) ->
+        // gT [D][ldT] in the contraction dtype, zero-padded beyond column B.  64 x 64 tiles through LDS; 8/16-byte
+        // reads along d, 8/16-byte writes along b.
+        // A third kind (blocks past the g tiles, only when the encoder GEMM gathered its rows itself and no staging
+        // launch ran): the batch rows of x (bf16, gathered through xrows) -> xT, the same way.
         float (*tile)[65] = (float (*)[65])sm;
-        const int t = blockIdx.x - nchunks;
+        int t = blockIdx.x - nchunks;
         const int ntb = ldT / 64;
+        const int ntr = ntb * ((D + 63) / 64);
+        const bool is_x = t >= ntr;
+        if (is_x) {
+            t -= ntr;
+            gT = xT;
+        }
         const int b0 = (t % ntb) * 64, d0 = (t / ntb) * 64;
         const int q = tid & 15, r16 = tid >> 4;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int bl = r16 + 16 * p, b = b0 + bl, d = d0 + 4 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b < B && d < D) v = *(const float4*)(g + (int64_t)b * D + d);
+            if (b < B && d < D) {
+                if (is_x) {
+                    const int64_t src = xrows ? (int64_t)xrows[b] : (int64_t)b;
+                    const bf16x4 t4 = *(const bf16x4*)(xsrc + src * D + d);
+                    v = make_float4((float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]);
+                } else if (gb) {
+                    const bf16x4 t4 = *(const bf16x4*)(gb + (int64_t)b * D + d);
+                    v = make_float4((float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]);
+                } else {
+                    v = *(const float4*)(g + (int64_t)b * D + d);
+                }
+            }
             tile[bl][4 * q] = v.x; tile[bl][4 * q + 1] = v.y; tile[bl][4 * q + 2] = v.z; tile[bl][4 * q + 3] = v.w;
         }
         __syncthreads();
@@ -440,6 +460,7 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
                    float* __restrict__ dbpre_out, unsigned long long* __restrict__ ticket) {
     __shared__ float red[8];
     __shared__ float e_s[DBPRE_ROWS];
+    __shared__ __attribute__((aligned(16))) float p_s[1024];  // row-part sums of a db_pre block (D <= 512: parts x D <= 1024)
     __shared__ int last_s;
     // the few latency-bound blocks (kinds two and three) take the first block ids so that they start
     // first and run under the streaming blocks instead of forming the tail of the launch
@@ -447,68 +468,120 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
     const int nlat = nblk_h + DBD_L1;
     const int bid = (int)blockIdx.x >= nlat ? (int)blockIdx.x - nlat : nrb + (int)blockIdx.x;
     if (bid < nrb) {
+        // one wave per row of the [2 H][D] gradient matrix (rows < H: dW_e, the rest dW_dT), `rpw` consecutive rows
+        // per wave: all slab loads of a row piece (8 independent 16-byte loads per lane) are in flight together -
+        // a loop over the splits with one load per trip ran at half the HBM rate
+        const int lane = tid & 63, wave = tid >> 6;
+        const int rows_total = 2 * H, nc = D >> 2;  // float4 chunks per row
+        const int rpw = (rows_total + nrb * 4 - 1) / (nrb * 4);
         float sq = 0.f;  // sum of squares of everything this block writes (global-norm partial)
-        const int64_t n4 = (int64_t)2 * H * D / 4;
-        const int64_t hd4 = (int64_t)H * D / 4;
-        for (int64_t i = (int64_t)bid * 256 + tid; i < n4; i += (int64_t)nrb * 256) {
-            float4 a = ((const float4*)slabs)[i];
-            for (int s = 1; s < nsplit; ++s) {
-                const float4 b = ((const float4*)(slabs + s * slab_stride))[i];
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-            }
-            if (i < hd4) {  // dW_e segment
-                const int64_t e = i * 4;
-                const int h = (int)(e / D), d = (int)(e - (int64_t)h * D);
-                float be = 0.f;
-                for (int s = 0; s < nsplit; ++s) be += dbe_slab[(int64_t)s * H + h];
-                if (d == 0) {
-                    dbe_out[h] = be;
+        for (int q = 0; q < rpw; ++q) {
+            const int r = (bid * 4 + wave) * rpw + q;
+            if (r >= rows_total) break;
+            float be = 0.f;
+            if (r < H) {  // db_e[h] = sum over splits, in split order (the db_pre blocks below use the same order)
+                const float v = lane < nsplit ? dbe_slab[(int64_t)lane * H + r] : 0.f;
+#pragma unroll
+                for (int sp = 0; sp < WSAE_WGRAD_MAX_SPLIT; ++sp) be += __shfl(v, sp, 64);
+                if (lane == 0) {
+                    dbe_out[r] = be;
                     sq = fmaf(be, be, sq);
                 }
-                if (FOLD) {
-                    const float4 bp = *(const float4*)(bpre + d);
+            }
+            const float4* base = (const float4*)slabs + (int64_t)r * nc;
+            for (int c = lane; c < nc; c += 64) {
+                float4 v[WSAE_WGRAD_MAX_SPLIT];
+#pragma unroll
+                for (int sp = 0; sp < WSAE_WGRAD_MAX_SPLIT; ++sp)  // splits past nsplit re-read the last one (weight 0)
+                    v[sp] = base[(int64_t)min(sp, nsplit - 1) * (slab_stride >> 2) + c];
+                float4 a = v[0];
+#pragma unroll
+                for (int sp = 1; sp < WSAE_WGRAD_MAX_SPLIT; ++sp) {
+                    const float w = sp < nsplit ? 1.f : 0.f;
+                    a.x = fmaf(w, v[sp].x, a.x); a.y = fmaf(w, v[sp].y, a.y);
+                    a.z = fmaf(w, v[sp].z, a.z); a.w = fmaf(w, v[sp].w, a.w);
+                }
+                if (FOLD && r < H) {
+                    const float4 bp = *(const float4*)(bpre + 4 * c);
                     a.x -= be * bp.x; a.y -= be * bp.y; a.z -= be * bp.z; a.w -= be * bp.w;
                 }
+                ((float4*)grads)[(int64_t)r * nc + c] = a;
+                sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
             }
-            ((float4*)grads)[i] = a;
-            sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
         }
         const float t = block_sum(sq, red);
         if (tid == 0) part_sq[bid] = t;
     } else if (bid < nrb + nblk_h) {
+        // db_pre partial of DBPRE_ROWS feature rows.  Work item = (row part, group of 4 columns): every thread streams
+        // its rows with 8/16-byte loads, 16 in flight; with D <= 512 the block's rows are split over 256 / (D / 4) parts
+        // whose sums meet in LDS.  (One thread per column walking all 128 rows with 2-byte loads was the tail of the
+        // launch.)
         const int blk = bid - nrb;
         const int h0 = blk * DBPRE_ROWS;
         if (tid < DBPRE_ROWS) {
             float be = 0.f;
             if (h0 + tid < H)
                 for (int s = 0; s < nsplit; ++s) be += dbe_slab[(int64_t)s * H + h0 + tid];  // same order as above
-            e_s[tid] = be;
+            e_s[tid] = be;  // (0 for rows past H)
         }
         __syncthreads();
-        for (int d = tid; d < D; d += 256) {
-            float a = 0.f;
-            for (int r0 = 0; r0 < DBPRE_ROWS; r0 += 32) {
-                float w[32];
+        const int ncg = D >> 2;
+        int nrp = 1;                                  // row parts: the largest power of two <= min(8, 256 / groups)
+        while (nrp < 8 && 2 * nrp * ncg <= 256) nrp *= 2;
+        const int rpp = DBPRE_ROWS / nrp;             // rows per part: a multiple of the 16-row load batch
+        for (int c = tid; c < ncg * nrp; c += 256) {
+            const int cg = c % ncg, rp = c / ncg;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r0 = rp * rpp; r0 < (rp + 1) * rpp; r0 += 16) {
+                float4 w[16];
 #pragma unroll
-                for (int i = 0; i < 32; ++i) w[i] = (float)W[(int64_t)min(h0 + r0 + i, H - 1) * D + d];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) a = fmaf(e_s[r0 + i], w[i], a);
-            }
-            __hip_atomic_store(part + (int64_t)blk * D + d, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else {
-        const int j = bid - nrb - nblk_h;
-        for (int d = tid; d < D; d += 256) {
-            float a = 0.f;
-            for (int t0 = 0; t0 < WSAE_MAX_PARTIALS / DBD_L1; t0 += 16) {
-                float v[16];
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int i = j + DBD_L1 * (t0 + t);
-                    v[t] = i < n_dec ? part_dbd[(int64_t)min(i, n_dec - 1) * D + d] : 0.f;
+                for (int i = 0; i < 16; ++i) {
+                    const TW* src = W + (int64_t)min(h0 + r0 + i, H - 1) * D + 4 * cg;
+                    if constexpr (sizeof(TW) == 2) {
+                        const bf16x4 t4 = *(const bf16x4*)src;
+                        w[i] = make_float4((float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]);
+                    } else {
+                        w[i] = *(const float4*)src;
+                    }
                 }
 #pragma unroll
-                for (int t = 0; t < 16; ++t) a += v[t];
+                for (int i = 0; i < 16; ++i) {
+                    const float e = e_s[r0 + i];
+                    a.x = fmaf(e, w[i].x, a.x); a.y = fmaf(e, w[i].y, a.y);
+                    a.z = fmaf(e, w[i].z, a.z); a.w = fmaf(e, w[i].w, a.w);
+                }
+            }
+            if (nrp == 1) {
+                float* dst = part + (int64_t)blk * D + 4 * cg;
+                __hip_atomic_store(dst, a.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, a.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 2, a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 3, a.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                *(float4*)(p_s + rp * D + 4 * cg) = a;
+            }
+        }
+        if (nrp > 1) {
+            __syncthreads();
+            for (int d = tid; d < D; d += 256) {
+                float a = 0.f;
+                for (int rp = 0; rp < nrp; ++rp) a += p_s[rp * D + d];
+                __hip_atomic_store(part + (int64_t)blk * D + d, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else {
+        // level-1 sums of the decode launch's per-block column sums: unconditional (clamped) loads, 16 in flight,
+        // rows past n_dec weighted 0 (a load under a per-element condition is a branch and a full wait each)
+        const int j = bid - nrb - nblk_h;
+        const int nterm = (n_dec + DBD_L1 - 1) / DBD_L1;
+        for (int d = tid; d < D; d += 256) {
+            float a = 0.f;
+            for (int t0 = 0; t0 < nterm; t0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) v[t] = part_dbd[(int64_t)min(j + DBD_L1 * (t0 + t), n_dec - 1) * D + d];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) a = fmaf(j + DBD_L1 * (t0 + t) < n_dec ? 1.f : 0.f, v[t], a);
             }
             __hip_atomic_store(dbd2 + (int64_t)j * D + d, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -521,27 +594,24 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
     }
     __syncthreads();
     if (!last_s) return;
+    // the last block to arrive finishes db_d and db_pre: every partial of a column is requested before any is summed
     float sq = 0.f;
     for (int d = tid; d < D; d += 256) {
         float sd = 0.f, sp = 0.f;
-        {
-            float v[DBD_L1];
+        float v[DBD_L1];
 #pragma unroll
-            for (int i = 0; i < DBD_L1; ++i)
-                v[i] = __hip_atomic_load(dbd2 + (int64_t)i * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < DBD_L1; ++i)
+            v[i] = __hip_atomic_load(dbd2 + (int64_t)i * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int b0 = 0; b0 < nblk_h; b0 += 32) {
+            float u[32];
 #pragma unroll
-            for (int i = 0; i < DBD_L1; ++i) sd += v[i];
+            for (int i = 0; i < 32; ++i)
+                u[i] = __hip_atomic_load(part + (int64_t)min(b0 + i, nblk_h - 1) * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sp = fmaf(b0 + i < nblk_h ? 1.f : 0.f, u[i], sp);
         }
-        for (int b0 = 0; b0 < nblk_h; b0 += 8) {
-            float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                v[i] = (b0 + i < nblk_h) ? __hip_atomic_load(part + (int64_t)min(b0 + i, nblk_h - 1) * D + d,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                         : 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sp += v[i];
-        }
+        for (int i = 0; i < DBD_L1; ++i) sd += v[i];
         const float p = sd - sp;
         dbd_out[d] = sd;
         dbpre_out[d] = p;
@@ -554,16 +624,10 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
 // Split-K factor.  A workgroup walks ceil(nchunks / nsplit) batch chunks and the grid runs in
 // ceil(tiles * nsplit / resident workgroups) rounds, so the kernel time goes like rounds * chunks per
 // split; every split also costs one slab written and re-read (the small per-split term).  At
-// H = 3072, D = 384, B = 16384 on 256 CUs this picks 5 (240 workgroups, one round of 52 chunks:
-// 121 us measured) over 8 (384 workgroups, two rounds of 32: 135 us) and 4 (139 us).
+// H = 3072, D = 384, B = 16384 (wgrad2_kernel: 32 tiles, one workgroup per CU) this picks 8: 256 workgroups,
+// one round of 32 chunks.
 static int pick_nsplit(wsae_ctx* ctx, int tiles, int nchunks, int nt) {
-    static int cus = 0;
-    if (!cus) {
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1)
-            cus = 256;
-    }
-    if (const char* e = getenv("WSAE_NSPLIT")) return max(1, min(WSAE_WGRAD_MAX_SPLIT, atoi(e)));  // experiments
-    const int resident = cus * (nt == 1 ? 2 : 1);  // LDS: 72 KB per workgroup at NT = 1, 108 / 144 KB above
+    const int resident = ctx->cus * (nt == 1 ? 2 : 1);  // LDS: 72 KB per workgroup at NT = 1, 108 / 144 KB above
     int best = 1;
     int64_t best_cost = INT64_MAX;
     for (int ns = 1; ns <= WSAE_WGRAD_MAX_SPLIT; ++ns) {
@@ -578,15 +642,18 @@ static int pick_nsplit(wsae_ctx* ctx, int tiles, int nchunks, int nt) {
 template <typename T>
 static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const float* vals, const int32_t* idx,
                          const float* dpre, int B, int ldT, int nsplit, int ntm, int ntn, float* out,
-                         int64_t slab_stride) {
+                         int64_t slab_stride, const void* x, const int32_t* rows) {
     constexpr int KT = Mfma<T>::KT;
     const int nchunks = ceil_div(B, KT);
     WSAE_PROF_BEGIN(ctx, WSAE_K_BUCKET, st);
     // + the transposition of g (left row-major by the decode launch) as a second kind of block in the same launch
+    // ... and, when no staging launch left xT (the encoder GEMM gathered the batch rows itself), of x as a third kind
     const int ntr = (ldT / 64) * ceil_div(ctx->D, 64);
-    bucket_kernel<T><<<nchunks + ntr, 256, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, nt == 0 ? W2_M : TILE_M, ctx->ent_pos,
-                                                    (T*)ctx->ent_hid, (T*)ctx->ent_dpre, ctx->ent_off, nchunks, ctx->g,
-                                                    (T*)ctx->gT, ctx->D, ldT);
+    const int nxt = ctx->xT_valid ? 0 : ntr;
+    bucket_kernel<T><<<nchunks + ntr + nxt, 256, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, nt == 0 ? W2_M : TILE_M, ctx->ent_pos,
+                                                          (T*)ctx->ent_hid, (T*)ctx->ent_dpre, ctx->ent_off, nchunks, ctx->g,
+                                                          ctx->g_is_bf16 ? ctx->gb : nullptr, (T*)ctx->gT, ctx->D, ldT,
+                                                          (const bf16_t*)x, rows, (T*)ctx->xT);
     WSAE_PROF_END(ctx, WSAE_K_BUCKET, st);
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD, st);
 #define WG_ARGS ctx->ent_pos, (const T*)ctx->ent_hid, (const T*)ctx->ent_dpre, ctx->ent_off, (const T*)ctx->xT, \
@@ -602,8 +669,10 @@ static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const
 extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                                  const int32_t* rows, const float* vals, const int32_t* idx, const float* dpre,
                                  int32_t B, float* grads, void* stream) {
-    (void)x; (void)x_dtype; (void)rows;  // the staged transposes in ctx (xT, gT) carry the batch
     WSAE_REQUIRE(ctx && params && vals && idx && dpre && grads, "wsae_weight_grads: null argument");
+    // x is read only when the forward skipped the staging launch (then it must be the same bf16 batch)
+    WSAE_REQUIRE(ctx->xT_valid || (x && x_dtype == WSAE_DT_BF16 && ctx->prec == WSAE_PREC_BF16),
+                 "wsae_weight_grads: the forward of this batch left no staged x^T and x is not a bf16 buffer");
     WSAE_REQUIRE(B >= 1 && B <= ctx->maxB, "wsae_weight_grads: batch %d outside [1, %d]", B, ctx->maxB);
     hipStream_t st = (hipStream_t)stream;
     const int D = ctx->D, H = ctx->H;
@@ -612,9 +681,8 @@ extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void*
     const int nchunks = ceil_div(B, kt);
     // column groups per workgroup: all of D in one workgroup when D is 2 or 3 tiles wide
     const int ncol = ceil_div(D, TILE_N);
-    // nt = 0 selects wgrad2_kernel (192 x 384 tiles) for wide inputs; WSAE_WGRAD_V1 keeps the 128-feature kernel
-    static const bool force_v1 = getenv("WSAE_WGRAD_V1") != nullptr;
-    const bool v2 = D > 256 && !force_v1;
+    // nt = 0 selects wgrad2_kernel (192 x 384 tiles) for wide inputs, the 128-feature kernel serves D <= 256
+    const bool v2 = D > 256;
     const int nt = v2 ? 0 : (ncol % 3 == 0) ? 3 : (ncol % 2 == 0) ? 2 : 1;
     const int ntm = v2 ? ceil_div(H, W2_M) : ceil_div(H, TILE_M);
     const int ntn = v2 ? ceil_div(D, W2_N) : ncol / nt;
@@ -624,14 +692,16 @@ extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void*
     dim3 grid(ntm * ntn * 2 * nsplit);
     float* out = ctx->wg_slabs;
     if (ctx->prec == WSAE_PREC_BF16)
-        launch_wgrad<bf16_t>(ctx, grid, nt, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride);
+        launch_wgrad<bf16_t>(ctx, grid, nt, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride, x, rows);
     else
-        launch_wgrad<float>(ctx, grid, nt, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride);
+        launch_wgrad<float>(ctx, grid, nt, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride, x, rows);
     WSAE_LAUNCH_CHECK();
 
     float* dbe = grads + ctx->off[2];
     const float* bpre = params + ctx->off[4];
-    const int nrb = (int)min((int64_t)WSAE_MAX_PARTIALS - 1, ceil_div64(slab_stride / 4, 256));
+    // reduction blocks: 8 rows of the [2 H][D] gradient matrix each (two per wave), more when 2 H / 8 would exceed the
+    // number of norm-partial slots
+    const int nrb = (int)min((int64_t)WSAE_MAX_PARTIALS - 1, ceil_div64(2 * (int64_t)H, 8));
     const int nblk = ceil_div(H, DBPRE_ROWS);
     unsigned long long* ticket = (unsigned long long*)(ctx->counters + 16 + 4 * TICKET_WORDS);
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD_REDUCE, st);

@@ -48,7 +48,7 @@ SIGNATURES = {
     "wsae_ctx_create": (C.c_int, [C.POINTER(Config), C.POINTER(_p)]),
     "wsae_ctx_destroy": (C.c_int, [_p]),
     "wsae_ctx_workspace_bytes": (C.c_size_t, [_p]),
-    "wsae_ctx_set_fused_topk": (C.c_int, [_p, _i32]),
+    "wsae_ctx_reserve_relu": (C.c_int, [_p]),
     "wsae_ctx_set_fired": (C.c_int, [_p, _p]),
     "wsae_prepare": (C.c_int, [_p, _p, _p]),
     "wsae_encode_topk": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
@@ -56,6 +56,7 @@ SIGNATURES = {
     "wsae_densify": (C.c_int, [_p, _p, _p, _i32, _p, _p]),
     "wsae_decode_dense": (C.c_int, [_p, _p, _p, _i32, _p, _p]),
     "wsae_decode_loss": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
+    "wsae_encode_decode": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "wsae_weight_grads": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     "wsae_input_grad": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p]),
     "wsae_adamw_step": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _i32,
@@ -146,7 +147,8 @@ def pack_layout(input_dim: int, hidden_dim: int) -> tuple:
     return 2 * d * h + h + 2 * d, off
 
 
-KERNEL_COUNT = 18
+KERNEL_COUNT = 12
+K_WGRAD = 5  # WSAE_K_WGRAD: the dominant kernel (bench.py's roofline object)
 
 
 def profile_read(handle: int) -> dict:

@@ -44,6 +44,7 @@ class SAEEngine:
         self._fresh: dict[int, bool] = {}  # precision -> derived shadows match the pack
         self.stats = torch.zeros(N.STATS_WORDS, dtype=torch.int32, device=self.device)
         self._work: dict = {}
+        self._relu_reserved: set = set()
 
     # -- pack views ----------------------------------------------------------------------------
     def view(self, name: str, base: torch.Tensor | None = None) -> torch.Tensor:
@@ -73,6 +74,7 @@ class SAEEngine:
         if have is not None:
             torch.cuda.synchronize(self.device)
             self.lib.wsae_ctx_destroy(have[0])
+            self._relu_reserved.discard(have[0])
         cap = max(int(batch), 64)
         cfg = N.Config(self.D, self.H, self.k, cap, precision, self.device.index or 0)
         handle = N._p()
@@ -82,6 +84,13 @@ class SAEEngine:
         self._fresh[precision] = False
         self.generation += 1  # a new ctx holds nobody's staged batch
         return handle.value
+
+    def reserve_relu(self, handle: int) -> None:
+        """Dense workspace of the ReLU path (allocated once per ctx, outside the launch functions)."""
+        if handle not in self._relu_reserved:
+            with torch.cuda.device(self.device):
+                N.check(self.lib.wsae_ctx_reserve_relu(handle), "wsae_ctx_reserve_relu")
+            self._relu_reserved.add(handle)
 
     def invalidate(self) -> None:
         """The pack changed outside ``wsae_adamw_step``: derived shadows must be rebuilt."""

@@ -74,12 +74,11 @@ class _TopKForward(torch.autograd.Function):
         last_ptr = module.feature_last_activated.data_ptr() if training else 0
         pk, xd = eng.pack.data_ptr(), _dtype_code(x2)
         N.check(lib.wsae_ctx_set_fired(handle, 0), "wsae_ctx_set_fired")  # the trainer's DDP clock exchange is per step
-        N.check(lib.wsae_encode_topk(handle, pk, x2.data_ptr(), xd, 0, B, vals.data_ptr(), idx.data_ptr(),
-                                     step_ptr, eng.stats.data_ptr(), st), "wsae_encode_topk")
-        N.check(lib.wsae_decode_loss(handle, pk, x2.data_ptr(), xd, 0, vals.data_ptr(), idx.data_ptr(), B,
-                                     recon.data_ptr(), 1 if need_bwd else 0, N.ptr(dpre), last_ptr,
-                                     module.step_count.data_ptr() if training else 0, eng.stats.data_ptr(), st),
-                "wsae_decode_loss")
+        # want_bwd: bit 0 = keep g / dpre for the weight gradients, bit 1 = also the fp32 g that dL/dx reads
+        want = (1 if need_bwd else 0) | (2 if (need_bwd and ctx.needs_input_grad[0]) else 0)
+        N.check(lib.wsae_encode_decode(handle, pk, x2.data_ptr(), xd, 0, B, vals.data_ptr(), idx.data_ptr(), step_ptr,
+                                       recon.data_ptr(), want, N.ptr(dpre), last_ptr, eng.stats.data_ptr(), st),
+                "wsae_encode_decode")
         hidden = torch.empty(B, eng.H, dtype=torch.float32, device=eng.device)
         N.check(lib.wsae_densify(handle, vals.data_ptr(), idx.data_ptr(), B, hidden.data_ptr(), st), "wsae_densify")
         sf = eng.stats_f32()
@@ -114,8 +113,9 @@ class _TopKForward(torch.autograd.Function):
             N.check(lib.wsae_encode_topk(handle, pk, x2.data_ptr(), xd, 0, B, tmp_v.data_ptr(), tmp_i.data_ptr(), 0,
                                          eng.stats.data_ptr(), st), "wsae_encode_topk")
             scratch = torch.zeros(N.STATS_WORDS, dtype=torch.int32, device=eng.device)
-            N.check(lib.wsae_decode_loss(handle, pk, x2.data_ptr(), xd, 0, vals.data_ptr(), idx.data_ptr(), B, 0, 1,
-                                         dpre.data_ptr(), 0, 0, scratch.data_ptr(), st), "wsae_decode_loss")
+            N.check(lib.wsae_decode_loss(handle, pk, x2.data_ptr(), xd, 0, vals.data_ptr(), idx.data_ptr(), B, 0,
+                                         3 if ctx.needs_input_grad[0] else 1, dpre.data_ptr(), 0, 0, scratch.data_ptr(), st),
+                    "wsae_decode_loss")
             eng.generation += 1
         grads = torch.empty(eng.P, dtype=torch.float32, device=eng.device)
         N.check(lib.wsae_weight_grads(handle, pk, x2.data_ptr(), xd, 0, vals.data_ptr(), idx.data_ptr(),
@@ -354,6 +354,7 @@ class _ReLUForward(torch.autograd.Function):
         x2 = x2.contiguous()
         B = x2.shape[0]
         handle = eng.prepare(prec, B, force=True)
+        eng.reserve_relu(handle)
         hidden = torch.empty(B, eng.H, dtype=torch.float32, device=eng.device)
         recon = torch.empty(B, eng.D, dtype=torch.float32, device=eng.device)
         sparsity = torch.empty((), dtype=torch.float32, device=eng.device)
@@ -377,6 +378,7 @@ class _ReLUForward(torch.autograd.Function):
         eng: SAEEngine = module._engine
         x2, hidden, recon = ctx.saved_tensors
         handle = eng.prepare(prec, B, force=True)
+        eng.reserve_relu(handle)
         pk, xd, st = eng.pack.data_ptr(), _dtype_code(x2), eng.stream()
         w = float(module.sparsity_weight)
         if eng.generation != ctx.gen:  # another forward reused the ctx workspace since: rebuild xT / hidden^T for this batch

@@ -1,7 +1,7 @@
 """``SAETrainer`` for MI355X -- the reference's trainer surface (src/whisper_sae/sae/training.py)
 on top of the fused HIP train step.
 
-One ``train_step`` = stage batch -> encode GEMM (MFMA) -> TopK -> sparse decode + MSE + dpre ->
+One ``train_step`` = stage batch -> encode GEMM (MFMA) -> [TopK + sparse decode + MSE + dpre] (MFMA, one launch) ->
 weight-gradient GEMMs (MFMA) -> [RCCL all-reduce under torch.distributed] -> clip + AdamW + decoder
 renorm -> dead-feature scan, all enqueued on the current HIP stream without a host sync.  The
 per-step scalars are written by the kernels into a device record and copied asynchronously to
@@ -236,11 +236,10 @@ class SAETrainer:
         step_ptr = model.step_count.data_ptr()
         ddp = world()[1] > 1
         N.check(lib.wsae_ctx_set_fired(handle, opt.fired.data_ptr() if ddp else 0), "wsae_ctx_set_fired")
-        N.check(lib.wsae_encode_topk(handle, pk, x.data_ptr(), xd, rp, B, w["vals"].data_ptr(), w["idx"].data_ptr(),
-                                     step_ptr, stats, st), "wsae_encode_topk")
-        N.check(lib.wsae_decode_loss(handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(), B, 0,
-                                     1, w["dpre"].data_ptr(), model.feature_last_activated.data_ptr(), step_ptr, stats,
-                                     st), "wsae_decode_loss")
+        # stage + encoder GEMM, then TopK + sparse decode + loss + dpre (one launch where the shape allows)
+        N.check(lib.wsae_encode_decode(handle, pk, x.data_ptr(), xd, rp, B, w["vals"].data_ptr(), w["idx"].data_ptr(),
+                                       step_ptr, 0, 1, w["dpre"].data_ptr(), model.feature_last_activated.data_ptr(),
+                                       stats, st), "wsae_encode_decode")
         N.check(lib.wsae_weight_grads(handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(),
                                       w["dpre"].data_ptr(), B, opt.grads.data_ptr(), st), "wsae_weight_grads")
         eng.generation += 1
@@ -263,6 +262,7 @@ class SAETrainer:
     def _train_step_relu(self, model, eng, handle, opt, x, rows, B, prec) -> TrainingMetrics:
         """ReLU + L1 step (reference ReLUSAE under training.py:161-217; no dead-feature bookkeeping)."""
         lib, st = eng.lib, eng.stream()
+        eng.reserve_relu(handle)
         w = eng.relu_work(B)
         pk, xd, rp = eng.pack.data_ptr(), _dtype_code(x), N.ptr(rows)
         chunk, slot = self._records.next(eng.device)
