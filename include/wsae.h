@@ -103,6 +103,10 @@ int wsae_ctx_destroy(wsae_ctx* ctx);
  * every rank).  Replaces the 8*H-byte MAX all-reduce the reference's semantics would otherwise need
  * under DDP (the reference itself is single-process). */
 int wsae_ctx_set_fired(wsae_ctx* ctx, float* fired);
+/* Number of columns the reconstruction MSE (and g = 2 r / (B cols)) averages over; default input_dim.  A transcoder
+ * whose output is narrower than its input runs on a ctx padded to the wider of the two and sets this to its
+ * output_dim (F.mse_loss means over B * output_dim, transcoder.py:152). */
+int wsae_ctx_set_loss_cols(wsae_ctx* ctx, int32_t cols);
 size_t wsae_ctx_workspace_bytes(const wsae_ctx* ctx);
 /* Allocate the dense workspace of the ReLU SAE path (3 x max_batch x hidden_dim operand copies) on the ctx's
  * device.  Call once after wsae_ctx_create, before the first wsae_relu_forward: launch functions never allocate. */
@@ -168,9 +172,14 @@ int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t
                       const int32_t* rows, const float* vals, const int32_t* idx,
                       const float* dpre, int32_t B, float* grads, void* stream);
 
-/* dL/dx (only the autograd API path needs it): dx = dpre W_e - g.  dx: [B,D] f32. */
+/* Copy of g = 2 (recon - x) / (B cols), fp32 [B, D], as left by the last wsae_decode_loss with want_bwd = 3: the
+ * gradient of the loss w.r.t. the reconstruction (= minus its gradient w.r.t. the target; transcoder skip path). */
+int wsae_last_residual_grad(wsae_ctx* ctx, int32_t B, float* g_out, void* stream);
+
+/* dL/dx (only the autograd API path needs it): dx = dpre W_e - g (subtract_g = 1: the SAE, whose target is its
+ * input; needs the fp32 g, want_bwd = 3) or dx = dpre W_e (subtract_g = 0: transcoders).  dx: [B,D] f32. */
 int wsae_input_grad(wsae_ctx* ctx, const float* params, const int32_t* idx, const float* dpre,
-                    int32_t B, float* dx, void* stream);
+                    int32_t B, float* dx, int32_t subtract_g, void* stream);
 
 /* ---- optimizer tail (training.py:186-198, :212) -------------------------------------------------
  * global-L2 clip (clip_grad_norm_, max_norm <= 0 disables) -> AdamW (torch semantics, step is the
@@ -207,13 +216,16 @@ int wsae_dead_scan(wsae_ctx* ctx, const int64_t* last_activated, const int64_t* 
  * goes to W_e[f,:] and W_dT[f,:], b_e[f] = 0, last_activated[f] = *step_count.  Adam moments
  * untouched.  n_dead_out (device int32): the capped dead count the reference returns
  * (model.py:257), even when fewer than that many rows exist. */
+/* Transcoders (sae/transcoder.py:207-252): wsae_row_errors takes the TARGET as x and may also leave the residual
+ * rows resid [Br, D] = x - recon (nullable); wsae_resample_dead then writes the L2-normalised row of dec_src
+ * (nullable: the residuals) into the decoder column instead of the input direction. */
 int wsae_row_errors(wsae_ctx* ctx, const void* x, int32_t x_dtype, const int32_t* rows,
-                    const float* recon, int32_t B, float* row_err, void* stream);
+                    const float* recon, int32_t B, float* row_err, float* resid, void* stream);
 int wsae_resample_dead(wsae_ctx* ctx, float* params, const void* inputs, int32_t x_dtype,
                        const int32_t* rows, int32_t Br, const float* row_err,
                        const uint8_t* dead_mask, int64_t* last_activated,
                        const int64_t* step_count, int32_t num_cap, int32_t* n_dead_out,
-                       void* stream);
+                       const float* dec_src, void* stream);
 
 /* ---- on-device activation ring buffer (replaces data/feature_cache.py:169-197) ---------------
  * capacity rows of D elements (bf16 or f32) resident in HBM; producers push blocks of rows,

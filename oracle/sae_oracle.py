@@ -435,3 +435,66 @@ def relu_backward(W_e, b_e, W_d, b_d, x, fwd: dict, sparsity_weight: float = 0.0
     db_e = dpre.sum(axis=0)
     return {"W_e": dW_e.astype(F32), "b_e": db_e.astype(F32), "W_d": dW_d.astype(F32),
             "b_d": db_d.astype(F32)}
+
+
+# --------------------------------------------------------------------------------------------
+# Transcoders  (sae/transcoder.py:32-422)
+# --------------------------------------------------------------------------------------------
+def transcoder_forward(W_e, b_e, W_d, b_d, k, x, target, mode: str = "fp32", skip_W=None, skip_b=None,
+                       select: np.ndarray | None = None) -> dict:
+    """transcoder.py:112-176 (TopKTranscoder) / :346-403 (SkipTranscoder when ``skip_W`` is given):
+    hidden = scatter(relu(topk(encoder(x)))); predicted = decoder(hidden) [+ skip(x)]; loss = mse(predicted, target).
+    ``"amp"`` mirrors the device's bf16 mode exactly as for the SAE (no pre-bias here); the skip path is fp32."""
+    x, target = np.asarray(x, dtype=F32), np.asarray(target, dtype=F32)
+    if mode == "amp":
+        pre = (bf16_round(x).astype(F64) @ bf16_round(W_e).astype(F64).T + b_e.astype(F64)).astype(F32)
+        w_d = bf16_round(W_d)
+    else:
+        pre = (x.astype(F64) @ W_e.astype(F64).T + b_e.astype(F64)).astype(F32)
+        w_d = W_d
+    if select is None:
+        vals, idx = topk_select(pre, k)
+    else:
+        idx = np.asarray(select, dtype=np.int64)
+        vals = np.take_along_axis(pre, idx, axis=1).astype(F32)
+    hidden = densify(vals, idx, W_e.shape[0])
+    sparse = (hidden.astype(F64) @ w_d.astype(F64).T + b_d.astype(F64)).astype(F32)
+    skip = None
+    if skip_W is not None:
+        skip = (x.astype(F64) @ skip_W.astype(F64).T + skip_b.astype(F64)).astype(F32)
+    pred = sparse if skip is None else (sparse.astype(F64) + skip.astype(F64)).astype(F32)
+    resid = pred.astype(F64) - target.astype(F64)
+    loss = F32(np.mean(resid * resid))
+    l0 = F32((hidden > 0).sum(axis=1).astype(F64).mean())
+    return {"pre": pre, "vals": vals, "idx": idx, "hidden": hidden, "predicted": pred, "loss": loss, "l0": l0}
+
+
+def transcoder_backward(W_e, b_e, W_d, b_d, x, target, fwd: dict, mode: str = "fp32", skip_W=None) -> dict:
+    """Autograd of the above: g = 2 (predicted - target) / (B out); dW_d = g^T hidden; db_d = sum g;
+    dpre = (g W_d) * 1[hidden > 0]; dW_e = dpre^T x; db_e = sum dpre; dx = dpre W_e [+ g W_skip];
+    dW_skip = g^T x; db_skip = sum g."""
+    x, target = np.asarray(x, dtype=F32), np.asarray(target, dtype=F32)
+    B, Dout = target.shape
+    hidden = fwd["hidden"].astype(F64)
+    g = (2.0 * (fwd["predicted"].astype(F64) - target.astype(F64)) / (B * Dout)).astype(F32)
+    g64 = g.astype(F64)
+    if mode == "amp":
+        dh = bf16_round(g).astype(F64) @ bf16_round(W_d).astype(F64)
+        dpre = bf16_round(np.where(hidden > 0, dh, 0.0).astype(F32)).astype(F64)
+        dW_d = bf16_round(g).astype(F64).T @ bf16_round(hidden.astype(F32)).astype(F64)
+        dW_e = dpre.T @ bf16_round(x).astype(F64)
+        dx = dpre @ W_e.astype(F64)
+    else:
+        dh = g64 @ W_d.astype(F64)
+        dpre = np.where(hidden > 0, dh, 0.0)
+        dW_d = g64.T @ hidden
+        dW_e = dpre.T @ x.astype(F64)
+        dx = dpre @ W_e.astype(F64)
+    out = {"W_e": dW_e.astype(F32), "b_e": dpre.sum(axis=0).astype(F32), "W_d": dW_d.astype(F32),
+           "b_d": g64.sum(axis=0).astype(F32), "g": g}
+    if skip_W is not None:
+        out["skip_W"] = (g64.T @ x.astype(F64)).astype(F32)
+        out["skip_b"] = g64.sum(axis=0).astype(F32)
+        dx = dx + g64 @ skip_W.astype(F64)
+    out["x"] = dx.astype(F32)
+    return out

@@ -18,6 +18,7 @@ Golden sets (SURVEY.md row C list):
   G7 resample_dead_features   G8 ReLUSAE fwd/grads    G9 API bookkeeping (keys, batch forms)
   G10 seeded initialisation (torch.manual_seed(42) -> TopKSAE / ReLUSAE parameters)
   G11 FeatureCache interchange: a cache written by the reference's FeatureCache.save (N1)
+  G12 transcoders: TopKTranscoder / SkipTranscoder forward, gradients, resample (N3)
 
 ``python tests/golden/make_golden.py g10 g11`` regenerates only the named sets.
 """
@@ -321,7 +322,72 @@ def g11_cache_interchange():
     meta_path.write_text(json.dumps(meta, indent=2))
 
 
-SETS = {"g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
+def g12_transcoders():
+    """TopKTranscoder / SkipTranscoder (sae/transcoder.py): forward, every gradient, and one resample call."""
+    from whisper_sae.sae.transcoder import SkipTranscoder, TopKTranscoder  # reference
+    out = {}
+    for tag, (Din, Dout, H, K, B) in {"eq": (64, 64, 256, 8, 48), "narrow": (64, 32, 128, 8, 40)}.items():
+        w = synth.sae_weights(Din, H, seed=23, bf16=False)
+        wd = synth.normal((Dout, H), 23, 33).astype(np.float64)
+        wd = (wd / np.sqrt((wd * wd).sum(axis=0, keepdims=True)) * 0.1).astype(np.float32)
+        bd = synth.uniform((Dout,), 23, 34, -0.05, 0.05)
+        x = synth.activations(B, Din, seed=23, stream=6, bf16=False)
+        tgt = synth.activations(B, Dout, seed=23, stream=7, bf16=False)
+        m = TopKTranscoder(Din, Dout, H, k=K, dead_feature_threshold=20)
+        sd = m.state_dict()
+        sd["encoder.weight"], sd["encoder.bias"] = torch.from_numpy(w["encoder.weight"]), torch.from_numpy(w["encoder.bias"])
+        sd["decoder.weight"], sd["decoder.bias"] = torch.from_numpy(wd), torch.from_numpy(bd)
+        m.load_state_dict(sd)
+        m.train()
+        xt = torch.from_numpy(x).requires_grad_(True)
+        o = m(xt, torch.from_numpy(tgt))
+        o.loss.backward()
+        out.update({f"{tag}.dims": np.array([Din, Dout, H, K, B]), f"{tag}.W_d": wd, f"{tag}.b_d": bd,
+                    f"{tag}.pred": o.predicted.detach().numpy(), f"{tag}.loss": np.float32(o.loss.item()),
+                    f"{tag}.l0": np.float32(o.l0.item()),
+                    f"{tag}.idx": np.sort(torch.topk(m.encoder(torch.from_numpy(x)), K, dim=-1).indices.numpy(), axis=1).astype(np.int16),
+                    f"{tag}.dW_e": m.encoder.weight.grad.numpy(), f"{tag}.db_e": m.encoder.bias.grad.numpy(),
+                    f"{tag}.dW_d": m.decoder.weight.grad.numpy(), f"{tag}.db_d": m.decoder.bias.grad.numpy(),
+                    f"{tag}.dx": xt.grad.numpy(), f"{tag}.step_count": np.int64(m.step_count.item()),
+                    f"{tag}.last_activated": m.feature_last_activated.numpy().copy()})
+        if tag == "eq":
+            # resample on a crafted dead state (train mode: the forward inside bumps the clock)
+            m2 = TopKTranscoder(Din, Dout, H, k=K, dead_feature_threshold=20)
+            m2.load_state_dict(sd)
+            m2.train()
+            with torch.no_grad():
+                m2.step_count.fill_(100)
+                la = torch.full((H,), 95, dtype=torch.long)
+                dead_idx = np.unique((synth.counter_u64(200, 23, 50) % np.uint64(H)).astype(np.int64))[:11]
+                la[torch.from_numpy(dead_idx)] = 3
+                m2.feature_last_activated.copy_(la)
+            ret = m2.resample_dead_features(torch.from_numpy(x), torch.from_numpy(tgt))
+            s2 = sd_numpy(m2)
+            out.update({"rs.ret": np.int64(ret), "rs.dead_idx": dead_idx, "rs.W_e": s2["encoder.weight"],
+                        "rs.b_e": s2["encoder.bias"], "rs.W_d": s2["decoder.weight"],
+                        "rs.last_activated": s2["feature_last_activated"], "rs.step_count": s2["step_count"]})
+            # skip transcoder with non-zero decoder / skip weights
+            sk = SkipTranscoder(Din, Dout, H, k=K)
+            ssd = sk.state_dict()
+            ssd.update({k_: v for k_, v in sd.items() if k_ in ssd})
+            ws = (synth.normal((Dout, Din), 23, 35) * np.float32(0.05)).astype(np.float32)
+            bs = synth.uniform((Dout,), 23, 36, -0.05, 0.05)
+            ssd["skip.weight"], ssd["skip.bias"] = torch.from_numpy(ws), torch.from_numpy(bs)
+            sk.load_state_dict(ssd)
+            sk.train()
+            xt = torch.from_numpy(x).requires_grad_(True)
+            o = sk(xt, torch.from_numpy(tgt))
+            o.loss.backward()
+            out.update({"skip.W_s": ws, "skip.b_s": bs, "skip.pred": o.predicted.detach().numpy(),
+                        "skip.loss": np.float32(o.loss.item()), "skip.dW_e": sk.encoder.weight.grad.numpy(),
+                        "skip.dW_d": sk.decoder.weight.grad.numpy(), "skip.db_d": sk.decoder.bias.grad.numpy(),
+                        "skip.dW_s": sk.skip.weight.grad.numpy(), "skip.db_s": sk.skip.bias.grad.numpy(),
+                        "skip.dx": xt.grad.numpy(),
+                        "skip.contribution": np.float64(sk.get_skip_contribution(torch.from_numpy(x), torch.from_numpy(tgt)))})
+    np.savez_compressed(HERE / "g12_transcoders.npz", **out)
+
+
+SETS = {"g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
         "g10": g10_seeded_init, "g11": g11_cache_interchange}
 
 if __name__ == "__main__":

@@ -314,3 +314,42 @@ class TestInterleavedCalls:
                "b_d": m.decoder.bias.grad, "b_pre": m.b_pre.grad}
         for n, g in got.items():
             assert rel(cpu(g), ora[n]) < 2e-5, (n, rel(cpu(g), ora[n]))
+
+
+class TestConfigs4:
+    """BASELINE.json configs[4] dimensions: 1280 -> 40960 ReLU + L1 (whisper-large-v3, 32x).  One trainer step in
+    bf16 mode against the float64 oracle's forward / backward on the same weights (ragged batch: the persistent
+    split-K GEMMs with a partly filled last tile)."""
+
+    def test_relu_step_at_1280_40960(self, device, tmp_path):
+        from whisper_sae.config import TrainingConfig
+        from whisper_sae.sae.model import ReLUSAE
+        from whisper_sae.sae.training import SAETrainer
+        D, H, B, weight = 1280, 40960, 600, 0.01
+        w = synth.sae_weights(D, H, seed=17, bf16=True)
+        m = ReLUSAE(D, H, sparsity_weight=weight)
+        sd = m.state_dict()
+        for key in ("encoder.weight", "encoder.bias", "decoder.weight", "decoder.bias"):
+            sd[key] = torch.from_numpy(w[key])
+        m.load_state_dict(sd)
+        cfg = TrainingConfig(batch_size=B, learning_rate=1e-4, weight_decay=0.0, epochs=1, warmup_steps=0,
+                             gradient_clip=1.0, use_amp=True, num_workers=0)
+        tr = SAETrainer(m, cfg, device=device, run_dir=tmp_path)
+        x = synth.activations(B, D, seed=17, stream=2, bf16=True)
+        met = tr.train_step(torch.from_numpy(x).to(device))
+        args = (w["encoder.weight"], w["encoder.bias"], w["decoder.weight"], w["decoder.bias"], x)
+        f = O.relu_forward(*args, sparsity_weight=weight)
+        gr = O.relu_backward(*args, f, sparsity_weight=weight)
+        d_loss = abs(met.loss - float(f["loss"])) / float(f["loss"])
+        d_l1 = abs(met.sparsity_loss - float(f["sparsity_loss"])) / float(f["sparsity_loss"])
+        assert d_loss < 5e-3 and d_l1 < 5e-3, (d_loss, d_l1)   # bf16 operands against the fp32 reference values
+        assert abs(met.l0 - float(f["l0"])) / float(f["l0"]) < 5e-3
+        d = {}
+        for n, key in (("W_e", "encoder.weight"), ("b_e", "encoder.bias"), ("W_d", "decoder.weight"),
+                       ("b_d", "decoder.bias")):
+            got, want = cpu(tr.optimizer.grad_view(key)).astype(np.float64), gr[n].astype(np.float64)
+            d[n] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+            assert d[n] < 2e-2, (n, d[n])
+        note("cfg5_relu_B600", {"d_loss": d_loss, "d_l1": d_l1, "grad_rel_l2": d})
+        cn = m.decoder.weight.detach().norm(dim=0)
+        assert torch.allclose(cn, torch.ones_like(cn), atol=1e-5)

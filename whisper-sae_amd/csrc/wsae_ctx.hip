@@ -80,6 +80,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
         return WSAE_ERR_NOMEM;
     }
     memset(c, 0, sizeof(*c));
+    c->loss_cols = D;
     c->D = D; c->H = H; c->K = K; c->maxB = maxB; c->prec = cfg->precision; c->device = cfg->device;
     if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || c->cus < 1)
         c->cus = 256;
@@ -234,6 +235,12 @@ extern "C" int wsae_profile_read(wsae_ctx* ctx, int32_t kernel_id, int32_t* n_la
 extern "C" int wsae_ctx_set_fired(wsae_ctx* ctx, float* fired) {
     WSAE_REQUIRE(ctx, "wsae_ctx_set_fired: null ctx");
     ctx->fired = fired;
+    return WSAE_OK;
+}
+
+extern "C" int wsae_ctx_set_loss_cols(wsae_ctx* ctx, int32_t cols) {
+    WSAE_REQUIRE(ctx && cols >= 1 && cols <= ctx->D, "wsae_ctx_set_loss_cols: columns must be in [1, input_dim]");
+    ctx->loss_cols = cols;
     return WSAE_OK;
 }
 

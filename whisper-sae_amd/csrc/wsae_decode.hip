@@ -31,12 +31,12 @@ decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const fl
               const int32_t* __restrict__ idx, int B, int D, int K, float* __restrict__ recon_out,
               float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated, float* __restrict__ fired,
               const int64_t* __restrict__ step_count, float* __restrict__ part_loss, float* __restrict__ part_l0,
-              float* __restrict__ part_dbd, int32_t* __restrict__ ticket, wsae_stats* __restrict__ stats) {
+              float* __restrict__ part_dbd, int32_t* __restrict__ ticket, wsae_stats* __restrict__ stats, int loss_cols) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;          // [8] block reduction scratch
     float* dbd_s = (float*)smem + 8;    // [4][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float scale = 2.0f / ((float)B * (float)D);
+    const float scale = 2.0f / ((float)B * (float)loss_cols);
     const int64_t step = (last_activated && step_count) ? *step_count : 0;
 
     // chunk c of this lane starts at column dcol[c]; chunks past D are clamped for loads and masked for results
@@ -157,7 +157,7 @@ decode_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, const fl
         __syncthreads();
     }
     __shared__ int last_flag;
-    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, &last_flag, part_loss, part_l0, part_dbd, ticket, stats);
+    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, loss_cols, red, &last_flag, part_loss, part_l0, part_dbd, ticket, stats);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -270,14 +270,14 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
                    float* __restrict__ dpre, float* __restrict__ g_out, int64_t* __restrict__ last_activated, float* __restrict__ fired,
                    const int64_t* __restrict__ step_count, float* __restrict__ part_loss,
                    float* __restrict__ part_l0, float* __restrict__ part_dbd, int32_t* __restrict__ ticket,
-                   wsae_stats* __restrict__ stats) {
+                   wsae_stats* __restrict__ stats, int loss_cols) {
     constexpr int D = 32 * EPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;        // [8]
     float* dbd_s = (float*)smem + 8;  // [4][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, li = lane & 31;
-    const float scale = 2.0f / ((float)B * (float)D);
+    const float scale = 2.0f / ((float)B * (float)loss_cols);
     const int64_t step = (last_activated && step_count) ? *step_count : 0;
 
     // b_d + b_pre and the per-wave column sums of g live in LDS, not in registers: the gathered rows
@@ -487,7 +487,7 @@ decode_fast_kernel(const TW* __restrict__ WdT, const float* __restrict__ bd, con
 
     __syncthreads();
     __shared__ int last_flag;
-    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, &last_flag, part_loss, part_l0, part_dbd, ticket, stats);
+    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, loss_cols, red, &last_flag, part_loss, part_l0, part_dbd, ticket, stats);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,7 +499,7 @@ static void launch_decode(wsae_ctx* c, const TW* WdT, const float* params, const
     const float* bpre = params + c->off[4];
     const size_t sh = (8 + 4 * (size_t)c->D) * sizeof(float);
 #define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->D, c->K, recon, dpre, c->g, last_activated, c->fired, step_count, \
-                 c->part_loss, c->part_l0, c->part_dbd, c->counters + 16 + 2 * TICKET_WORDS, stats
+                 c->part_loss, c->part_l0, c->part_dbd, c->counters + 16 + 2 * TICKET_WORDS, stats, c->loss_cols
     if (!want_bwd)
         decode_kernel<TW, EPL, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
     else if (c->prec == WSAE_PREC_BF16)
@@ -517,7 +517,7 @@ static void launch_decode_fast(wsae_ctx* c, const TW* WdT, const float* params, 
     const float* bpre = params + c->off[4];
     const size_t sh = (8 + 5 * (size_t)c->D) * sizeof(float);
 #define DEC_ARGS WdT, bd, bpre, x, rows, vals, idx, B, c->K, recon, dpre, c->g, last_activated, c->fired, step_count, \
-                 c->part_loss, c->part_l0, c->part_dbd, c->counters + 16 + 2 * TICKET_WORDS, stats
+                 c->part_loss, c->part_l0, c->part_dbd, c->counters + 16 + 2 * TICKET_WORDS, stats, c->loss_cols
     if (!want_bwd)
         decode_fast_kernel<TW, EPL, KJ, XDT, false, false><<<nblk, 256, sh, st>>>(DEC_ARGS);
     else if (c->prec == WSAE_PREC_BF16)
@@ -630,6 +630,16 @@ extern "C" int wsae_encode_decode(wsae_ctx* ctx, const float* params, const void
                          st);
 }
 
+// g = 2 (recon - target) / (B cols) of the last decode launch, fp32 [B, D] (kept when want_bwd had bit 1 set): the
+// gradient of the loss with respect to the reconstruction; a transcoder's skip path trains through it.
+extern "C" int wsae_last_residual_grad(wsae_ctx* ctx, int32_t B, float* g_out, void* stream) {
+    WSAE_REQUIRE(ctx && g_out && B >= 1 && B <= ctx->maxB, "wsae_last_residual_grad: bad argument");
+    WSAE_REQUIRE(ctx->g32_valid, "wsae_last_residual_grad: the preceding decode did not keep the fp32 g (pass want_bwd = 3)");
+    WSAE_HIP_CHECK(hipMemcpyAsync(g_out, ctx->g, (size_t)B * ctx->D * sizeof(float), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return WSAE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // dL/dx = dpre W_e - g      (autograd API path only; model.py:108,145)
 // ------------------------------------------------------------------------------------------------
@@ -640,7 +650,7 @@ __global__ void __launch_bounds__(256) input_grad_kernel(const float* __restrict
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     for (int d = lane; d < D; d += 64) {
-        float a = -g[(int64_t)b * D + d];
+        float a = g ? -g[(int64_t)b * D + d] : 0.f;  // (g null: the target is not the input - transcoders)
         for (int j = 0; j < K; ++j) {
             const float dp = dpre[(int64_t)b * K + j];
             if (dp != 0.f) a = fmaf(dp, We[(int64_t)idx[(int64_t)b * K + j] * D + d], a);
@@ -650,11 +660,11 @@ __global__ void __launch_bounds__(256) input_grad_kernel(const float* __restrict
 }
 
 extern "C" int wsae_input_grad(wsae_ctx* ctx, const float* params, const int32_t* idx, const float* dpre, int32_t B,
-                               float* dx, void* stream) {
+                               float* dx, int32_t subtract_g, void* stream) {
     WSAE_REQUIRE(ctx && params && idx && dpre && dx && B >= 1 && B <= ctx->maxB, "wsae_input_grad: bad argument");
-    WSAE_REQUIRE(ctx->g32_valid, "wsae_input_grad: the preceding decode did not keep the fp32 g (pass want_bwd = 3)");
-    input_grad_kernel<<<ceil_div(B, 4), 256, 0, (hipStream_t)stream>>>(params + ctx->off[0], ctx->g, idx, dpre, B, ctx->D,
-                                                                       ctx->K, dx);
+    WSAE_REQUIRE(!subtract_g || ctx->g32_valid, "wsae_input_grad: the preceding decode did not keep the fp32 g (pass want_bwd = 3)");
+    input_grad_kernel<<<ceil_div(B, 4), 256, 0, (hipStream_t)stream>>>(params + ctx->off[0], subtract_g ? ctx->g : nullptr, idx, dpre,
+                                                                       B, ctx->D, ctx->K, dx);
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;
 }

@@ -11,7 +11,7 @@
 
 template <bool BWD>
 __device__ __forceinline__ void decode_block_epilogue(float loss_acc, int l0_acc, const float* dbd_s, int D, int B,
-                                                      float* red, int* flag, float* part_loss, float* part_l0,
+                                                      int loss_cols, float* red, int* flag, float* part_loss, float* part_l0,
                                                       float* part_dbd, int32_t* ticket, wsae_stats* stats) {
     const int lane = threadIdx.x & 63;
     const float bl = block_sum(loss_acc, red);
@@ -40,7 +40,7 @@ __device__ __forceinline__ void decode_block_epilogue(float loss_acc, int l0_acc
     const float ta = block_sum(a, red);
     const float tc = block_sum(c, red);
     if (threadIdx.x == 0) {
-        stats->loss = ta / ((float)B * (float)D);
+        stats->loss = ta / ((float)B * (float)loss_cols);  // mean over the REAL output columns (transcoders may pad D)
         stats->l0 = tc / (float)B;
     }
 }

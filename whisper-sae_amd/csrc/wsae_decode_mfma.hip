@@ -126,7 +126,7 @@ decode_mfma_kernel(const bf16_t* __restrict__ WdT, const float* __restrict__ bd,
                    float* __restrict__ g32_out, bf16_t* __restrict__ gb_out, int64_t* __restrict__ last_activated,
                    float* __restrict__ fired, const int64_t* __restrict__ step_count, float* __restrict__ part_loss,
                    float* __restrict__ part_l0, float* __restrict__ part_dbd, int32_t* __restrict__ ticket,
-                   wsae_stats* __restrict__ stats) {
+                   wsae_stats* __restrict__ stats, int loss_cols) {
     constexpr int D = 128 * NSUB;
     constexpr int KP = 32 * KS;      // feature slots per row (K padded)
     constexpr int E = KP / 4;        // DMA wave-instructions per piece
@@ -156,7 +156,7 @@ decode_mfma_kernel(const bf16_t* __restrict__ WdT, const float* __restrict__ bd,
         bsum2[s] = f32x2{a.x + p.x, a.y + p.y};
     }
 
-    const float scale = 2.0f / ((float)B * (float)D);
+    const float scale = 2.0f / ((float)B * (float)loss_cols);
     const int64_t step = (last_activated && step_count) ? *step_count : 0;
     constexpr bool x_bf16 = XDT == WSAE_DT_BF16;
     // lane-constant LDS offsets (the slot and the tile / k-step enter as uniform or compile-time terms):
@@ -400,7 +400,7 @@ decode_mfma_kernel(const bf16_t* __restrict__ WdT, const float* __restrict__ bd,
         for (int s = 0; s < NSUB; ++s) *(float2*)(dbd_s + wave * D + 128 * s + 2 * lane) = make_float2(dbd[s][0], dbd[s][1]);
     }
     __syncthreads();
-    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, red, flag_s, part_loss, part_l0, part_dbd, ticket, stats);
+    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, loss_cols, red, flag_s, part_loss, part_l0, part_dbd, ticket, stats);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -422,7 +422,7 @@ static int dm_launch(wsae_ctx* c, const float* params, const void* x, const int3
     const int nblk = min(ceil_div(B, 4), min(per_cu[want_bwd ? 1 : 0] * c->cus, WSAE_MAX_PARTIALS));
 #define DM_ARGS c->WdT_bf16, params + c->off[3], params + c->off[4], x, rows, vals, idx, B, c->K, recon, dpre, g32, \
                 c->gb, last_activated, c->fired, step_count, c->part_loss, c->part_l0, c->part_dbd,                       \
-                c->counters + 16 + 2 * TICKET_WORDS, stats
+                c->counters + 16 + 2 * TICKET_WORDS, stats, c->loss_cols
     if (want_bwd) decode_mfma_kernel<KS, NSUB, XDT, true><<<nblk, 256, sh, st>>>(DM_ARGS);
     else decode_mfma_kernel<KS, NSUB, XDT, false><<<nblk, 256, sh, st>>>(DM_ARGS);
 #undef DM_ARGS

@@ -437,7 +437,7 @@ extern "C" int wsae_dead_scan(wsae_ctx* ctx, const int64_t* last_activated, cons
 template <int XDT>
 __global__ void __launch_bounds__(256) row_err_kernel(const void* __restrict__ x, const int32_t* __restrict__ rows,
                                                       const float* __restrict__ recon, int B, int D,
-                                                      float* __restrict__ row_err) {
+                                                      float* __restrict__ row_err, float* __restrict__ resid) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -446,19 +446,20 @@ __global__ void __launch_bounds__(256) row_err_kernel(const void* __restrict__ x
     for (int d = lane; d < D; d += 64) {
         const float r = load_act<XDT>(x, src * D + d) - recon[(int64_t)b * D + d];
         s = fmaf(r, r, s);
+        if (resid) resid[(int64_t)b * D + d] = r;  // target - predicted (transcoder.py:236)
     }
     s = wave_sum(s);
     if (lane == 0) row_err[b] = s;
 }
 
 extern "C" int wsae_row_errors(wsae_ctx* ctx, const void* x, int32_t x_dtype, const int32_t* rows, const float* recon,
-                               int32_t B, float* row_err, void* stream) {
+                               int32_t B, float* row_err, float* resid, void* stream) {
     WSAE_REQUIRE(ctx && x && recon && row_err && B >= 1, "wsae_row_errors: bad argument");
     hipStream_t st = (hipStream_t)stream;
     if (x_dtype == WSAE_DT_F32)
-        row_err_kernel<WSAE_DT_F32><<<ceil_div(B, 4), 256, 0, st>>>(x, rows, recon, B, ctx->D, row_err);
+        row_err_kernel<WSAE_DT_F32><<<ceil_div(B, 4), 256, 0, st>>>(x, rows, recon, B, ctx->D, row_err, resid);
     else
-        row_err_kernel<WSAE_DT_BF16><<<ceil_div(B, 4), 256, 0, st>>>(x, rows, recon, B, ctx->D, row_err);
+        row_err_kernel<WSAE_DT_BF16><<<ceil_div(B, 4), 256, 0, st>>>(x, rows, recon, B, ctx->D, row_err, resid);
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;
 }
@@ -531,7 +532,8 @@ __global__ void __launch_bounds__(256)
 resample_write_kernel(const void* __restrict__ inputs, const int32_t* __restrict__ rows, int Br, int D,
                       const int32_t* __restrict__ dead_list, const int32_t* __restrict__ n_dead,
                       const int32_t* __restrict__ order, float* __restrict__ We, float* __restrict__ WdT,
-                      float* __restrict__ be, int64_t* __restrict__ last, const int64_t* __restrict__ step_count) {
+                      float* __restrict__ be, int64_t* __restrict__ last, const int64_t* __restrict__ step_count,
+                      const float* __restrict__ dec_src) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = min(*n_dead, Br);
@@ -546,10 +548,22 @@ resample_write_kernel(const void* __restrict__ inputs, const int32_t* __restrict
     }
     s = wave_sum(s);
     const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+    // decoder column: the same direction (SAE, model.py:251), or the L2-normalised row r of dec_src (transcoders write
+    // the normalised residual there, transcoder.py:247-249)
+    float invd = inv;
+    if (dec_src) {
+        float sd = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float v = dec_src[(int64_t)r * D + d];
+            sd = fmaf(v, v, sd);
+        }
+        sd = wave_sum(sd);
+        invd = 1.f / fmaxf(sqrtf(sd), 1e-12f);
+    }
     for (int d = lane; d < D; d += 64) {
-        const float v = load_act<XDT>(inputs, src * D + d) * inv;
-        We[(int64_t)f * D + d] = v;
-        WdT[(int64_t)f * D + d] = v;
+        const float v = load_act<XDT>(inputs, src * D + d);
+        We[(int64_t)f * D + d] = v * inv;
+        WdT[(int64_t)f * D + d] = dec_src ? dec_src[(int64_t)r * D + d] * invd : v * inv;
     }
     if (lane == 0) {
         be[f] = 0.f;
@@ -560,7 +574,7 @@ resample_write_kernel(const void* __restrict__ inputs, const int32_t* __restrict
 extern "C" int wsae_resample_dead(wsae_ctx* ctx, float* params, const void* inputs, int32_t x_dtype,
                                   const int32_t* rows, int32_t Br, const float* row_err, const uint8_t* dead_mask,
                                   int64_t* last_activated, const int64_t* step_count, int32_t num_cap,
-                                  int32_t* n_dead_out, void* stream) {
+                                  int32_t* n_dead_out, const float* dec_src, void* stream) {
     WSAE_REQUIRE(ctx && params && inputs && row_err && dead_mask && last_activated && step_count && n_dead_out,
                  "wsae_resample_dead: null argument");
     WSAE_REQUIRE(Br >= 1, "wsae_resample_dead: empty resample batch");
@@ -582,10 +596,10 @@ extern "C" int wsae_resample_dead(wsae_ctx* ctx, float* params, const void* inpu
         float* be = params + ctx->off[2];
         if (x_dtype == WSAE_DT_F32)
             resample_write_kernel<WSAE_DT_F32><<<ceil_div(nwork, 4), 256, 0, st>>>(
-                inputs, rows, Br, D, ctx->dead_list, n_dead_out, ctx->row_order, We, WdT, be, last_activated, step_count);
+                inputs, rows, Br, D, ctx->dead_list, n_dead_out, ctx->row_order, We, WdT, be, last_activated, step_count, dec_src);
         else
             resample_write_kernel<WSAE_DT_BF16><<<ceil_div(nwork, 4), 256, 0, st>>>(
-                inputs, rows, Br, D, ctx->dead_list, n_dead_out, ctx->row_order, We, WdT, be, last_activated, step_count);
+                inputs, rows, Br, D, ctx->dead_list, n_dead_out, ctx->row_order, We, WdT, be, last_activated, step_count, dec_src);
         WSAE_LAUNCH_CHECK();
     }
     return wsae_prepare_launch(ctx, params, st);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "wsae_ctx_create": (C.c_int, [C.POINTER(Config), C.POINTER(_p)]),
     "wsae_ctx_destroy": (C.c_int, [_p]),
     "wsae_ctx_workspace_bytes": (C.c_size_t, [_p]),
+    "wsae_ctx_set_loss_cols": (C.c_int, [_p, _i32]),
     "wsae_ctx_reserve_relu": (C.c_int, [_p]),
     "wsae_ctx_set_fired": (C.c_int, [_p, _p]),
     "wsae_prepare": (C.c_int, [_p, _p, _p]),
@@ -58,13 +59,14 @@ SIGNATURES = {
     "wsae_decode_loss": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
     "wsae_encode_decode": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "wsae_weight_grads": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p]),
-    "wsae_input_grad": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p]),
+    "wsae_last_residual_grad": (C.c_int, [_p, _i32, _p, _p]),
+    "wsae_input_grad": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i32, _p]),
     "wsae_adamw_step": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _i32,
                                   _p, _p, _i64, _p, _p]),
     "wsae_normalize_decoder": (C.c_int, [_p, _p, _p]),
     "wsae_dead_scan": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p]),
-    "wsae_row_errors": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _p, _p]),
-    "wsae_resample_dead": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _i32, _p, _p]),
+    "wsae_row_errors": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _p, _p, _p]),
+    "wsae_resample_dead": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _p]),
     "wsae_ring_create": (C.c_int, [_i32, _i64, _i32, _i32, C.POINTER(_p)]),
     "wsae_ring_destroy": (C.c_int, [_p]),
     "wsae_ring_data": (_p, [_p]),

@@ -1,6 +1,8 @@
-"""Sparse autoencoders and their trainer (MI355X build)."""
+"""Sparse autoencoders, transcoders and their trainer (MI355X build)."""
 
 from .model import ReLUSAE, SAEOutput, TopKSAE, create_sae
 from .training import RingBatch, SAETrainer, TrainingMetrics
+from .transcoder import SkipTranscoder, TopKTranscoder, TranscoderOutput, create_transcoder
 
-__all__ = ["ReLUSAE", "SAEOutput", "TopKSAE", "create_sae", "RingBatch", "SAETrainer", "TrainingMetrics"]
+__all__ = ["ReLUSAE", "SAEOutput", "TopKSAE", "create_sae", "RingBatch", "SAETrainer", "TrainingMetrics",
+           "SkipTranscoder", "TopKTranscoder", "TranscoderOutput", "create_transcoder"]

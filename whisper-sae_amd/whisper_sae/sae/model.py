@@ -125,7 +125,7 @@ class _TopKForward(torch.autograd.Function):
         dx = None
         if need[0]:
             dx = torch.empty(B, eng.D, dtype=torch.float32, device=eng.device)
-            N.check(lib.wsae_input_grad(handle, pk, idx.data_ptr(), dpre.data_ptr(), B, dx.data_ptr(), st),
+            N.check(lib.wsae_input_grad(handle, pk, idx.data_ptr(), dpre.data_ptr(), B, dx.data_ptr(), 1, st),
                     "wsae_input_grad")
             dx = (dx * g_loss).reshape(ctx.x_shape)
         gv = lambda name, on: eng.view(name, grads) if on else None  # noqa: E731
@@ -326,13 +326,13 @@ class TopKSAE(nn.Module):
                 "wsae_decode_loss")
         row_err = torch.empty(Br, dtype=torch.float32, device=eng.device)
         eng.generation += 1
-        N.check(lib.wsae_row_errors(handle, x2.data_ptr(), xd, 0, recon.data_ptr(), Br, row_err.data_ptr(), st),
+        N.check(lib.wsae_row_errors(handle, x2.data_ptr(), xd, 0, recon.data_ptr(), Br, row_err.data_ptr(), 0, st),
                 "wsae_row_errors")
         n_out = torch.zeros(1, dtype=torch.int32, device=eng.device)
         cap = -1 if num_resample is None else int(num_resample)
         N.check(lib.wsae_resample_dead(handle, pk, x2.data_ptr(), xd, 0, Br, row_err.data_ptr(), mask.data_ptr(),
                                        self.feature_last_activated.data_ptr(), self.step_count.data_ptr(), cap,
-                                       n_out.data_ptr(), st), "wsae_resample_dead")
+                                       n_out.data_ptr(), 0, st), "wsae_resample_dead")
         eng.invalidate()
         return int(n_out.item())
 
