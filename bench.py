@@ -29,6 +29,7 @@ for _p in (str(ROOT), str(ROOT / "whisper-sae_amd")):
 D_MODEL, HIDDEN, TOPK = 384, 3072, 32
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"  # written by profiles/tools/profile_step.sh on this build
 
 
 def cpu_baseline(batch: int, budget_s: float = 20.0) -> dict:
@@ -74,6 +75,7 @@ def main() -> None:
     ap.add_argument("--ring-rows", type=int, default=1 << 22)
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the median is reported")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel (adds event overhead)")
     ap.add_argument("--dims", type=int, nargs=3, metavar=("D", "H", "K"), default=None,
                     help="informational: other SAE dimensions (e.g. 768 12288 64 = BASELINE.json configs[3]); no roofline object")
@@ -115,7 +117,7 @@ def main() -> None:
     ring = ActivationRing(args.ring_rows, D_MODEL, device=device, dtype=ring_dtype)
     ring.fill_synthetic(args.ring_rows, seed=42 + rank)  # every rank owns its own shard of rows
     loader = RingLoader(ring, B, shuffle=True, seed=42)
-    total = args.warmup + 2 * args.steps + 8
+    total = args.warmup + (args.windows + 1) * args.steps + 8
     trainer.setup_scheduler(max(total, 20000))
 
     def batches():
@@ -139,19 +141,25 @@ def main() -> None:
     # events around the dominant kernel only (two event records per step) inside the timed region
     dominant = N.lib().wsae_kernel_name  # noqa: F841
     kid = -1 if args.profile_all else N.K_WGRAD
-    N.check(N.lib().wsae_profile_enable(handle, kid, args.steps), "wsae_profile_enable")
+    N.check(N.lib().wsae_profile_enable(handle, kid, args.steps * args.windows), "wsae_profile_enable")
 
-    barrier()
-    t0 = time.perf_counter()
+    # windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both
+    # sides and reduced with MAX over ranks; the median window is the reported one, all of them are listed.
     last = None
-    for _ in range(args.steps):
-        last = trainer.train_step(next(it))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    windows = []
+    for _ in range(max(args.windows, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = trainer.train_step(next(it))
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        windows.append(el)
+    elapsed = sorted(windows)[len(windows) // 2]
 
     prof = N.profile_read(handle)
     N.check(N.lib().wsae_profile_disable(handle), "wsae_profile_disable")
@@ -165,19 +173,31 @@ def main() -> None:
         roof = None
         if n_w and not args.dims and not args.relu:
             flops_per_launch = 2 * (2.0 * HIDDEN * D_MODEL * B)
-            # HBM bytes per launch of this kernel from the PMC passes committed under profiles/
-            # (r01_v3_pmc_traffic.csv: 2 x FETCH_SIZE + WRITE_SIZE); measured at the default configuration only
-            traffic = 100.7e6 if (B == 16384 and args.precision == "bf16") else None
+            # HBM bytes per launch of this kernel: the FETCH_SIZE / WRITE_SIZE PMC passes of this build committed
+            # under profiles/ (profiles/tools/profile_step.sh; PMC cannot be collected inside a timed run).  Only
+            # valid at the configuration the passes were run at.
+            traffic, traffic_src = None, None
+            pmc = ROOT / "profiles" / PMC_TRAFFIC_FILE
+            if B == 16384 and args.precision == "bf16" and pmc.exists():
+                rec = json.loads(pmc.read_text())["kernels"].get("wgrad2_kernel")
+                if rec:
+                    traffic, traffic_src = rec["hbm_bytes"], f"profiles/{PMC_TRAFFIC_FILE} (2 x FETCH_SIZE + WRITE_SIZE, median per launch)"
             achieved = flops_per_launch / (ms_w / n_w * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "wgrad2_kernel<bf16>", "achieved": achieved,
                     "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
-                    "traffic": traffic, "avg_launch_ms": ms_w / n_w, "launches": n_w,
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": ms_w / n_w, "launches": n_w,
+                    "flops_per_launch": flops_per_launch,
                     "step_dense_equiv_tflops": value * f_dense / 1e12,
-                    "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS}
+                    "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                    # what the step really issues on MFMA: encoder GEMM 2*D*H + the two weight-gradient
+                    # contractions 4*D*H per activation (the decode and dpre products are sparse, k rows each)
+                    "f_exec_per_activation": 6 * D_MODEL * HIDDEN,
+                    "step_mfma_exec_frac": value * 6 * D_MODEL * HIDDEN / 1e12 / BF16_DENSE_PEAK_TFLOPS}
         out = {
             "metric": f"activations/sec through SAE train step (d={D_MODEL}->{HIDDEN}, " + ("relu+l1)" if args.relu else f"k={TOPK})"),
             "value": value, "unit": "activations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "windows_ms_per_step": [w / args.steps * 1e3 for w in windows],
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": (f"ReLUSAE {D_MODEL}->{HIDDEN} (sparsity_weight 0.01) train step, informational" if args.relu else
                                     f"TopKSAE {D_MODEL}->{HIDDEN} k={TOPK} train step, informational" if args.dims else

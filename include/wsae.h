@@ -269,6 +269,21 @@ int wsae_profile_enable(wsae_ctx* ctx, int32_t kernel_id, int32_t max_samples);
 int wsae_profile_disable(wsae_ctx* ctx);
 int wsae_profile_read(wsae_ctx* ctx, int32_t kernel_id, int32_t* n_launches, double* total_ms);
 
+/* ---- per-feature top activations (row N4: analysis/feature_viz.py:94-158, TopKTracker.update) -----------------
+ * The consumer right after the path: for every feature keep the `keep` (<= 64) strongest positive activations seen
+ * so far.  One call = one batch of `rows` activation rows, given either as the compact code the TopK kernel emits
+ * (vals/idx [rows][width], width = k) or as a dense matrix (idx == NULL, vals [rows][H], width == H).  Row r of the
+ * call is activation number ord_base + r; the caller maps ordinals to (sample, position).  State (caller-owned,
+ * zero-initialised, device memory on the current device): top_vals [H][keep] f32 and top_ord [H][keep] i64, both
+ * sorted (value descending, then ordinal ascending: the reference keeps the earlier of two equal values,
+ * feature_viz.py:153), top_cnt [H] i32, total_active [1] i64 (+= number of entries > 0, feature_viz.py:136).
+ * workspace: wsae_feature_topk_workspace_bytes(rows * width, H) bytes of scratch. */
+int64_t wsae_feature_topk_workspace_bytes(int64_t max_entries, int32_t H);
+int wsae_feature_topk_update(const float* vals, const int32_t* idx, int64_t rows, int32_t width, int32_t H,
+                             int32_t keep, int64_t ord_base, float* top_vals, int64_t* top_ord,
+                             int32_t* top_cnt, int64_t* total_active, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
 /* ---- ReLU SAE (model.py:260-322), dense path ------------------------------------------------- */
 /* ReLUSAE has no pre-bias: pass the TopK pack [W_e | W_dT | b_e | b_d | b_pre] with b_pre = 0 (wsae_prepare
  * first, as for the TopK path).  forward:  hidden [B,H] f32 = relu(x W_e^T + b_e) (model.py:307),

@@ -19,6 +19,7 @@ Golden sets (SURVEY.md row C list):
   G10 seeded initialisation (torch.manual_seed(42) -> TopKSAE / ReLUSAE parameters)
   G11 FeatureCache interchange: a cache written by the reference's FeatureCache.save (N1)
   G12 transcoders: TopKTranscoder / SkipTranscoder forward, gradients, resample (N3)
+  G13 per-feature top activations: the reference's TopKTracker over three updates (N4)
 
 ``python tests/golden/make_golden.py g10 g11`` regenerates only the named sets.
 """
@@ -387,7 +388,47 @@ def g12_transcoders():
     np.savez_compressed(HERE / "g12_transcoders.npz", **out)
 
 
-SETS = {"g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
+def g13_feature_topk():
+    """analysis/feature_viz.py:59-250: TopKTracker fed three batches (dense [B,H], sequence [B,T,H], dense again)
+    of sparse positive activations without equal values; stored: the inputs and every feature's kept
+    (value, sample, position) list, strongest first, plus the counters."""
+    from whisper_sae.analysis.feature_viz import TopKTracker  # reference
+    H, KEEP = 96, 5
+    shapes = [(40, 1), (6, 7), (33, 1)]
+    tracker = TopKTracker(num_features=H, k=KEEP)
+    out = {"H": np.array(H), "keep": np.array(KEEP)}
+    sample0 = 0
+    for u, (b, t) in enumerate(shapes):
+        n = b * t * H
+        raw = synth.counter_u64(n, 13, 10 + u)
+        # distinct positive values (the counter index breaks every tie), about one entry in five active
+        val = ((raw >> np.uint64(40)).astype(np.float64) + 1.0) / float(1 << 24) + np.arange(n) * 2.0 ** -30
+        act = np.where((raw % np.uint64(5)) == 0, val, 0.0).astype(np.float32).reshape(b, t, H)
+        assert len(np.unique(act[act > 0])) == int((act > 0).sum())
+        samples = list(range(sample0, sample0 + b))
+        sample0 += b
+        tracker.update(torch.from_numpy(act[:, 0] if t == 1 else act), samples,
+                       transcriptions=[f"utt{s}" for s in samples])
+        out[f"act{u}"] = act
+        out[f"samples{u}"] = np.array(samples)
+    vals = np.zeros((H, KEEP), np.float32)
+    samp = np.full((H, KEEP), -1, np.int64)
+    pos = np.full((H, KEEP), -1, np.int64)
+    cnt = np.zeros(H, np.int32)
+    for f in range(H):
+        ex = tracker.get_top_examples(f)
+        cnt[f] = len(ex)
+        for j, e in enumerate(ex):
+            vals[f, j], samp[f, j], pos[f, j] = e.activation_value, e.sample_idx, e.position_idx
+            assert e.transcription == f"utt{e.sample_idx}" and e.timestamp_ms == e.position_idx * 10.0
+    out.update(vals=vals, samples=samp, positions=pos, counts=cnt, total_activations=np.array(tracker.total_activations),
+               samples_processed=np.array(tracker.samples_processed))
+    st = tracker.get_feature_stats()
+    out["stats_mean"] = np.array([st[f]["mean_activation"] for f in range(H)], np.float64)
+    np.savez_compressed(HERE / "g13_feature_topk.npz", **out)
+
+
+SETS = {"g13": g13_feature_topk, "g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
         "g10": g10_seeded_init, "g11": g11_cache_interchange}
 
 if __name__ == "__main__":

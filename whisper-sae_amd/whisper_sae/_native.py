@@ -56,6 +56,8 @@ SIGNATURES = {
     "wsae_encode_dense": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p]),
     "wsae_densify": (C.c_int, [_p, _p, _p, _i32, _p, _p]),
     "wsae_decode_dense": (C.c_int, [_p, _p, _p, _i32, _p, _p]),
+    "wsae_feature_topk_workspace_bytes": (_i64, [_i64, _i32]),
+    "wsae_feature_topk_update": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _i64, _p]),
     "wsae_decode_loss": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
     "wsae_encode_decode": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "wsae_weight_grads": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p]),
