@@ -199,6 +199,8 @@ int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void*
                                  int B, float* pre, int64_t* step_count, int direct, hipStream_t st);
 // internal (wsae_encode.hip): the standalone TopK launch over ctx->pre; whether the strip-guided form applies
 int wsae_internal_topk(wsae_ctx* ctx, int B, float* vals, int32_t* idx, int32_t* fb, hipStream_t st);
+int wsae_internal_encode_topk(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,
+                              float* vals, int32_t* idx, int64_t* step_count, int32_t* fb, hipStream_t st);
 bool wsae_internal_strips_ok(const wsae_ctx* ctx);
 // internal (wsae_decode_mfma.hip): the MFMA decode kernel (BF16 mode)
 bool wsae_internal_decode_mfma_ok(const wsae_ctx* c);

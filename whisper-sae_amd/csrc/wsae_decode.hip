@@ -622,9 +622,7 @@ extern "C" int wsae_encode_decode(wsae_ctx* ctx, const float* params, const void
                                "wsae_encode_decode");
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    rc = wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, step_count, 1, st);
-    if (rc) return rc;
-    rc = wsae_internal_topk(ctx, B, vals, idx, &stats->topk_fallback_rows, st);
+    rc = wsae_internal_encode_topk(ctx, params, x, x_dtype, rows, B, vals, idx, step_count, &stats->topk_fallback_rows, st);
     if (rc) return rc;
     return decode_launch(ctx, params, x, x_dtype, rows, vals, idx, B, recon, want_bwd, dpre, last_activated, step_count, stats,
                          st);

@@ -549,6 +549,14 @@ int wsae_internal_topk(wsae_ctx* ctx, int B, float* vals, int32_t* idx, int32_t*
     return WSAE_OK;
 }
 
+// encoder + TopK of one batch: the dense GEMM into ctx->pre followed by a TopK launch
+int wsae_internal_encode_topk(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,
+                              float* vals, int32_t* idx, int64_t* step_count, int32_t* fb, hipStream_t st) {
+    int rc = wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, step_count, 1, st);
+    if (rc) return rc;
+    return wsae_internal_topk(ctx, B, vals, idx, fb, st);
+}
+
 extern "C" int wsae_encode_topk(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                                 const int32_t* rows, int32_t B, float* vals, int32_t* idx, int64_t* step_count,
                                 wsae_stats* stats, void* stream) {
@@ -557,9 +565,7 @@ extern "C" int wsae_encode_topk(wsae_ctx* ctx, const float* params, const void* 
     WSAE_REQUIRE(params && vals && idx, "wsae_encode_topk: null argument");
     hipStream_t st = (hipStream_t)stream;
     int32_t* fb = stats ? &stats->topk_fallback_rows : ctx->counters;
-    rc = wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, step_count, 1, st);
-    if (rc) return rc;
-    return wsae_internal_topk(ctx, B, vals, idx, fb, st);
+    return wsae_internal_encode_topk(ctx, params, x, x_dtype, rows, B, vals, idx, step_count, fb, st);
 }
 
 extern "C" int wsae_densify(wsae_ctx* ctx, const float* vals, const int32_t* idx, int32_t B, float* hidden,
