@@ -76,6 +76,8 @@ def main() -> None:
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the median is reported")
+    ap.add_argument("--grad-exchange", choices=("fp32", "bf16"), default="fp32",
+                    help="N > 1: dtype of the gradient all-reduce (default fp32, the exact data-parallel gradient)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel (adds event overhead)")
     ap.add_argument("--dims", type=int, nargs=3, metavar=("D", "H", "K"), default=None,
                     help="informational: other SAE dimensions (e.g. 768 12288 64 = BASELINE.json configs[3]); no roofline object")
@@ -111,7 +113,8 @@ def main() -> None:
     torch.manual_seed(42)  # same initial weights on every rank (scripts/train.py:84-90 seeds before create_sae)
     model = ReLUSAE(D_MODEL, HIDDEN, sparsity_weight=0.01) if args.relu else TopKSAE(D_MODEL, HIDDEN, k=TOPK)
     cfg = TrainingConfig(batch_size=B, learning_rate=1e-4, weight_decay=0.0, warmup_steps=1000, gradient_clip=1.0,
-                         use_amp=(args.precision == "bf16"), num_workers=0, seed=42)
+                         use_amp=(args.precision == "bf16"), num_workers=0, seed=42,
+                         grad_exchange_dtype=args.grad_exchange)
     trainer = SAETrainer(model, cfg, device=device, run_dir=ROOT / "gpurun_out" / f"bench_rank{rank}")
     ring_dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
     ring = ActivationRing(args.ring_rows, D_MODEL, device=device, dtype=ring_dtype)
@@ -205,7 +208,8 @@ def main() -> None:
                                    "activations resident in the HBM ring buffer" + ("" if world == 1 else
                                    f" (configs[2]: DDP x{world}, RCCL grad all-reduce)"),
                        "batch_per_gpu": B, "global_batch": world * B, "ring_rows_per_gpu": args.ring_rows,
-                       "lr": 1e-4, "clip": 1.0, "parallelism": f"dp{world}"},
+                       "lr": 1e-4, "clip": 1.0, "parallelism": f"dp{world}",
+                       **({"grad_exchange": args.grad_exchange} if world > 1 else {})},
             "roofline": roof,
             "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS,
             "final_loss": last.loss if last is not None else None,

@@ -57,8 +57,13 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
         fired = (local == step).to(torch.float32)  # what the decode kernel stores: 1.0 where this rank stamped the clock
         last = torch.from_numpy(clocks_before.copy())  # every rank starts the step with the agreed clocks
         flat = torch.cat([grads, fired])
+        wire = flat.clone()
         scale = sync_gradients(flat)
         assert scale == 1.0 / world
+        # the optional bf16 exchange (TrainingConfig.grad_exchange_dtype = "bf16"): the same sum to bf16 accuracy,
+        # the fired indicators exactly
+        assert sync_gradients(wire, torch.bfloat16) == scale
+        np.save(os.path.join(out_dir, f"w{rank}.npy"), wire.numpy())
         last = merge_clock(last, flat[grads.numel():], step)
         flat = flat[:grads.numel()]
         np.save(os.path.join(out_dir, f"g{rank}.npy"), (flat * scale).numpy())
@@ -87,6 +92,11 @@ def test_two_rank_gradient_average_equals_full_batch(tmp_path):
     assert np.abs(g0 - want).max() <= 2e-6 * np.abs(want).max()
     l0, l1 = np.load(tmp_path / "l0.npy"), np.load(tmp_path / "l1.npy")
     assert np.array_equal(l0, l1) and np.array_equal(l0, st.last_activated)
+    w0, w1 = np.load(tmp_path / "w0.npy"), np.load(tmp_path / "w1.npy")
+    n = want.size
+    assert np.array_equal(w0, w1)
+    assert np.abs(w0[:n] / world - want).max() <= 2.0 ** -7 * np.abs(want).max()
+    assert np.array_equal(w0[n:] > 0, l0 == int(st.step_count))  # fired sums survive the bf16 wire exactly
 
 
 def test_single_process_is_a_no_op():

@@ -27,15 +27,25 @@ def world():
     return None, 1
 
 
-def sync_gradients(flat: torch.Tensor) -> float:
+def sync_gradients(flat: torch.Tensor, exchange_dtype: torch.dtype = torch.float32) -> float:
     """Sum ``flat`` (gradient pack, optionally followed by the fired indicators) over all ranks, in place.
+
+    ``exchange_dtype=torch.bfloat16`` (``TrainingConfig.grad_exchange_dtype = "bf16"``, off by default) sends the
+    buffer as bf16 - half the bytes over xGMI, what PyTorch DDP's ``bf16_compress_hook`` does: every rank rounds its
+    gradients to bf16, RCCL sums in bf16, the sum is widened back.  The fired indicators (sums of at most
+    ``world_size`` ones) survive exactly; the gradients carry a relative error of about 2^-8 per addend.
 
     Returns the factor the caller must scale the summed gradients by (``1 / world_size``).
     """
     dist, n = world()
     if dist is None:
         return 1.0
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if exchange_dtype == torch.float32:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    else:
+        wire = flat.to(exchange_dtype)
+        dist.all_reduce(wire, op=dist.ReduceOp.SUM)
+        flat.copy_(wire)
     return 1.0 / n
 
 

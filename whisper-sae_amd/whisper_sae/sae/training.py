@@ -138,6 +138,7 @@ class SAETrainer:
 
         on_gpu = str(device).startswith("cuda")
         self.use_amp = bool(config.use_amp and on_gpu)  # bf16 MFMA contractions when set, fp32 MFMA otherwise
+        self._exchange_dtype = torch.bfloat16 if getattr(config, "grad_exchange_dtype", "fp32") == "bf16" else torch.float32
         self.scaler = torch.amp.GradScaler("cuda", enabled=False)  # bf16 needs no loss scaling
 
         self.global_step = 0
@@ -245,7 +246,7 @@ class SAETrainer:
         eng.generation += 1
         # data parallel: ONE RCCL all-reduce of [gradients | fired indicators]; the optimizer kernel applies
         # 1/world and stamps the dead-feature clock of every feature that fired on any rank
-        grad_scale = sync_gradients(opt.grads_ext) if ddp else 1.0
+        grad_scale = sync_gradients(opt.grads_ext, self._exchange_dtype) if ddp else 1.0
         opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=grad_scale,
                  normalize_decoder=True, batch=B, norm_from_wgrad=(grad_scale == 1.0), dead_scan=True,
                  stats_ptr=stats)
@@ -273,7 +274,7 @@ class SAETrainer:
         N.check(lib.wsae_relu_backward(handle, pk, x.data_ptr(), xd, rp, B, weight, w["hidden"].data_ptr(),
                                        w["recon"].data_ptr(), opt.grads.data_ptr(), st), "wsae_relu_backward")
         eng.generation += 1
-        grad_scale = sync_gradients(opt.grads) if world()[1] > 1 else 1.0
+        grad_scale = sync_gradients(opt.grads, self._exchange_dtype) if world()[1] > 1 else 1.0
         opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=grad_scale,
                  normalize_decoder=bool(model.normalize_decoder), batch=B, norm_from_wgrad=False, dead_scan=False,
                  stats_ptr=stats)
