@@ -234,6 +234,11 @@ int wsae_resample_dead(wsae_ctx* ctx, float* params, const void* inputs, int32_t
 int wsae_ring_create(int32_t device, int64_t capacity_rows, int32_t dim, int32_t dtype,
                      wsae_ring** out);
 int wsae_ring_destroy(wsae_ring* ring);
+/* Producer side (row N2, sae/hooks.py:86-92): rows of hidden states [n_rows, dim] go through LayerNorm(gamma, beta, eps;
+ * biased variance, as torch.nn.LayerNorm - Whisper's final encoder / decoder norm) and into the ring in its dtype,
+ * one pass, nothing on the host. */
+int wsae_ring_push_layernorm(wsae_ring* ring, const void* src, int32_t src_dtype, int64_t n_rows,
+                             const float* gamma, const float* beta, float eps, void* stream);
 void* wsae_ring_data(wsae_ring* ring);         /* device pointer of row 0 */
 int64_t wsae_ring_size(const wsae_ring* ring); /* rows currently valid */
 /* append n_rows rows ([n_rows, D], device pointer, src_dtype f32/bf16 -> converted to the ring's

@@ -20,6 +20,7 @@ Golden sets (SURVEY.md row C list):
   G11 FeatureCache interchange: a cache written by the reference's FeatureCache.save (N1)
   G12 transcoders: TopKTranscoder / SkipTranscoder forward, gradients, resample (N3)
   G13 per-feature top activations: the reference's TopKTracker over three updates (N4)
+  G14 activation producer: extract_features_batch on a seeded random-init tiny Whisper (N2)
 
 ``python tests/golden/make_golden.py g10 g11`` regenerates only the named sets.
 """
@@ -428,7 +429,35 @@ def g13_feature_topk():
     np.savez_compressed(HERE / "g13_feature_topk.npz", **out)
 
 
-SETS = {"g13": g13_feature_topk, "g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
+def tiny_whisper(seed: int = 0):
+    """A random-init Whisper small enough for a fixture (no pretrained weights exist offline); same code in
+    tests/test_hooks.py builds the same model from the same seed."""
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    cfg = WhisperConfig(vocab_size=200, num_mel_bins=80, encoder_layers=2, decoder_layers=2, encoder_attention_heads=2,
+                        decoder_attention_heads=2, encoder_ffn_dim=128, decoder_ffn_dim=128, d_model=64,
+                        max_source_positions=50, max_target_positions=16, decoder_start_token_id=1, pad_token_id=0,
+                        bos_token_id=1, eos_token_id=2)
+    torch.manual_seed(seed)
+    return WhisperForConditionalGeneration(cfg).eval()
+
+
+def g14_hooks():
+    """sae/hooks.py:147-230: extract_features_batch (with and without the final LayerNorm) on the seeded tiny model."""
+    import transformers
+    from whisper_sae.sae.hooks import extract_features_batch, flatten_activations  # reference
+    model = tiny_whisper(0)
+    mel = synth.normal((2, 80, 100), 14, 1).astype(np.float32)
+    out = {"mel": mel, "transformers_version": np.array(transformers.__version__), "torch_version": np.array(torch.__version__)}
+    for tag, ln in (("ln", True), ("raw", False)):
+        r = extract_features_batch(model, torch.from_numpy(mel), [0, 1], [0, 1], ln, "cpu")
+        for comp in ("encoder", "decoder"):
+            for layer, t in r[comp].items():
+                out[f"{tag}.{comp}.{layer}"] = t.numpy()
+        out[f"{tag}.flat"] = flatten_activations(r["encoder"][1], "encoder").numpy()
+    np.savez_compressed(HERE / "g14_hooks.npz", **out)
+
+
+SETS = {"g14": g14_hooks, "g13": g13_feature_topk, "g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
         "g10": g10_seeded_init, "g11": g11_cache_interchange}
 
 if __name__ == "__main__":

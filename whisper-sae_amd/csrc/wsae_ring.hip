@@ -83,6 +83,79 @@ extern "C" int wsae_ring_push(wsae_ring* ring, const void* src, int32_t src_dtyp
     return WSAE_OK;
 }
 
+// ---- producer side: the final LayerNorm of the Whisper stack applied to a block of hidden
+// states on their way into the ring - one wave per row: mean and variance by wave reductions (two passes over the
+// row held in registers), then gamma * (v - mean) * rstd + beta written in the ring's dtype.  Replaces
+// layer_norm(activation).cpu() -> list -> torch.cat -> disk of /root/reference/src/whisper_sae/sae/hooks.py:86-92.
+template <int SRC, int DST, int VPL>
+__global__ void __launch_bounds__(256) ring_push_ln_kernel(const void* __restrict__ src, void* __restrict__ dst,
+                                                           int64_t n_rows, int dim, int64_t head, int64_t cap,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    float v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int d = lane + 64 * i;
+        v[i] = 0.f;
+        if (d < dim) v[i] = SRC == WSAE_DT_F32 ? ((const float*)src)[r * dim + d] : (float)((const bf16_t*)src)[r * dim + d];
+        sum += v[i];
+    }
+    const float mean = wave_sum(sum) / (float)dim;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float c = lane + 64 * i < dim ? v[i] - mean : 0.f;
+        sq = fmaf(c, c, sq);
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)dim + eps);  // biased variance, as torch.nn.LayerNorm
+    const int64_t slot = (head + r) % cap;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int d = lane + 64 * i;
+        if (d < dim) {
+            const float y = (v[i] - mean) * rstd * gamma[d] + beta[d];
+            if (DST == WSAE_DT_F32) ((float*)dst)[slot * dim + d] = y;
+            else ((bf16_t*)dst)[slot * dim + d] = (bf16_t)y;
+        }
+    }
+}
+
+extern "C" int wsae_ring_push_layernorm(wsae_ring* ring, const void* src, int32_t src_dtype, int64_t n_rows,
+                                        const float* gamma, const float* beta, float eps, void* stream) {
+    WSAE_REQUIRE(ring && src && gamma && beta && n_rows >= 0, "wsae_ring_push_layernorm: bad argument");
+    WSAE_REQUIRE(src_dtype == WSAE_DT_F32 || src_dtype == WSAE_DT_BF16, "wsae_ring_push_layernorm: unknown dtype %d", src_dtype);
+    WSAE_REQUIRE(ring->dim <= 2048, "wsae_ring_push_layernorm: row width %d > 2048", ring->dim);
+    if (n_rows == 0) return WSAE_OK;
+    if (n_rows > ring->cap) {  // only the newest cap rows can survive
+        const int64_t skip = n_rows - ring->cap;
+        src = (const char*)src + (size_t)skip * ring->dim * (src_dtype == WSAE_DT_BF16 ? 2 : 4);
+        ring->head = (ring->head + skip) % ring->cap;
+        n_rows = ring->cap;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = (unsigned)ceil_div64(n_rows, 4);
+#define PUSH_LN(S, D_, V) ring_push_ln_kernel<S, D_, V><<<nb, 256, 0, st>>>(src, ring->data, n_rows, ring->dim, ring->head, ring->cap, gamma, beta, eps)
+#define PUSH_LN_V(S, D_)                               \
+    do {                                               \
+        if (ring->dim <= 512) PUSH_LN(S, D_, 8);       \
+        else PUSH_LN(S, D_, 32);                       \
+    } while (0)
+    if (src_dtype == WSAE_DT_F32 && ring->dtype == WSAE_DT_F32) PUSH_LN_V(WSAE_DT_F32, WSAE_DT_F32);
+    else if (src_dtype == WSAE_DT_F32) PUSH_LN_V(WSAE_DT_F32, WSAE_DT_BF16);
+    else if (ring->dtype == WSAE_DT_F32) PUSH_LN_V(WSAE_DT_BF16, WSAE_DT_F32);
+    else PUSH_LN_V(WSAE_DT_BF16, WSAE_DT_BF16);
+#undef PUSH_LN_V
+#undef PUSH_LN
+    WSAE_LAUNCH_CHECK();
+    ring->head = (ring->head + n_rows) % ring->cap;
+    ring->size = min(ring->cap, ring->size + n_rows);
+    return WSAE_OK;
+}
+
 // ---- seeded shuffle: a bijection of [0, n) --------------------------------------------------------
 // Feistel network on the enclosing power-of-two domain, cycle-walked back into [0, n).
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {

@@ -74,6 +74,7 @@ SIGNATURES = {
     "wsae_ring_data": (_p, [_p]),
     "wsae_ring_size": (_i64, [_p]),
     "wsae_ring_push": (C.c_int, [_p, _p, _i32, _i64, _p]),
+    "wsae_ring_push_layernorm": (C.c_int, [_p, _p, _i32, _i64, _p, _p, _f32, _p]),
     "wsae_ring_sample": (C.c_int, [_p, C.c_uint64, _i64, _i64, _i32, _p, _p]),
     "wsae_ring_fill_synthetic": (C.c_int, [_p, C.c_uint64, _i64, _p]),
     "wsae_kernel_name": (C.c_char_p, [_i32]),

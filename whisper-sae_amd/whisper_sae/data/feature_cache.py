@@ -111,6 +111,23 @@ class ActivationRing:
                     "wsae_ring_push")
             torch.cuda.current_stream(self.device).synchronize()  # `part` must outlive the copy kernel
 
+    def push_layernorm(self, hidden: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5) -> None:
+        """``LayerNorm(hidden)`` rows straight into the ring (one kernel: normalise, cast, store; row N2).
+
+        ``hidden``: device tensor ``[..., dim]`` (the hooked layer's output), ``weight`` / ``bias``: the LayerNorm's
+        parameters (Whisper's final encoder / decoder norm, reference sae/hooks.py:86-88)."""
+        rows = hidden.detach().reshape(-1, self.dim)
+        if rows.device != self.device:
+            raise N.WsaeError("push_layernorm takes hidden states that already live on the ring's device")
+        if rows.dtype not in (torch.float32, torch.bfloat16):
+            rows = rows.float()
+        rows = rows.contiguous()
+        w = weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        b = bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        N.check(self.lib.wsae_ring_push_layernorm(self._h, rows.data_ptr(), _dtype_code(rows), rows.shape[0], w.data_ptr(),
+                                                  b.data_ptr(), float(eps), self._stream()), "wsae_ring_push_layernorm")
+        rows.record_stream(torch.cuda.current_stream(self.device))
+
     def fill_synthetic(self, n_rows: int, seed: int = 42) -> None:
         N.check(self.lib.wsae_ring_fill_synthetic(self._h, C.c_uint64(seed), int(n_rows), self._stream()),
                 "wsae_ring_fill_synthetic")
