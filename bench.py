@@ -81,6 +81,7 @@ def main() -> None:
     ap.add_argument("--profile-all", action="store_true", help="time every kernel (adds event overhead)")
     ap.add_argument("--dims", type=int, nargs=3, metavar=("D", "H", "K"), default=None,
                     help="informational: other SAE dimensions (e.g. 768 12288 64 = BASELINE.json configs[3]); no roofline object")
+    ap.add_argument("--fp8", action="store_true", help="with --relu: e4m3 operands in the two forward GEMMs (configs[4])")
     ap.add_argument("--relu", action="store_true", help="informational: ReLU+L1 SAE step (row A12) instead of the TopK "
                                                         "headline; no roofline object")
     args = ap.parse_args()
@@ -111,7 +112,8 @@ def main() -> None:
 
     B = args.batch
     torch.manual_seed(42)  # same initial weights on every rank (scripts/train.py:84-90 seeds before create_sae)
-    model = ReLUSAE(D_MODEL, HIDDEN, sparsity_weight=0.01) if args.relu else TopKSAE(D_MODEL, HIDDEN, k=TOPK)
+    model = (ReLUSAE(D_MODEL, HIDDEN, sparsity_weight=0.01, precision="fp8" if args.fp8 else None) if args.relu
+             else TopKSAE(D_MODEL, HIDDEN, k=TOPK))
     cfg = TrainingConfig(batch_size=B, learning_rate=1e-4, weight_decay=0.0, warmup_steps=1000, gradient_clip=1.0,
                          use_amp=(args.precision == "bf16"), num_workers=0, seed=42,
                          grad_exchange_dtype=args.grad_exchange)
@@ -202,7 +204,7 @@ def main() -> None:
             "ms_per_step": elapsed / args.steps * 1e3, "windows_ms_per_step": [w / args.steps * 1e3 for w in windows],
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": (f"ReLUSAE {D_MODEL}->{HIDDEN} (sparsity_weight 0.01) train step, informational" if args.relu else
+            "config": {"workload": (f"ReLUSAE {D_MODEL}->{HIDDEN} (sparsity_weight 0.01{', fp8 forward GEMMs' if args.fp8 else ''}) train step, informational" if args.relu else
                                     f"TopKSAE {D_MODEL}->{HIDDEN} k={TOPK} train step, informational" if args.dims else
                                     "BASELINE.json configs[1]: TopKSAE 384->3072 k=32 train step") + ", synthetic "
                                    "activations resident in the HBM ring buffer" + ("" if world == 1 else

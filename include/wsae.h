@@ -297,6 +297,12 @@ int wsae_feature_topk_update(const float* vals, const int32_t* idx, int64_t rows
  * NULL, as may stats).  backward (must follow the forward of the same batch on the same ctx: it reuses the
  * staged x^T and hidden^T): grads in pack layout, dW_e, dW_dT, db_e, db_d as autograd of model.py:304-311
  * gives them, the b_pre slot set to 0; no dL/dx (the reference has none either).  Needs wsae_ctx_reserve_relu. */
+/* configs[4] of BASELINE.json ("fp8 MFMA encode/decode"): on != 0 makes the two forward GEMMs of wsae_relu_forward take
+ * OCP e4m3 copies of their operands (x and hidden quantised per batch row, W_e per feature row, W_d per output row;
+ * q = e4m3(v * 448 / amax_row), v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulate, dequantised in the GEMM epilogue).  BF16
+ * mode only; hidden, loss and the whole backward stay on the bf16 path.  Needs batch >= 512, input_dim % 256 == 0,
+ * hidden_dim % 256 == 0. */
+int wsae_ctx_set_relu_fp8(wsae_ctx* ctx, int32_t on);
 int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                       const int32_t* rows, int32_t B, float sparsity_weight, float* hidden,
                       float* recon, wsae_stats* stats, float* sparsity_loss_out, void* stream);

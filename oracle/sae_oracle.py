@@ -405,12 +405,48 @@ def resample_dead_features(st: SAEState, inputs: np.ndarray, num_resample: int |
 # --------------------------------------------------------------------------------------------
 # ReLU SAE  (model.py:260-322)
 # --------------------------------------------------------------------------------------------
-def relu_forward(W_e, b_e, W_d, b_d, x, sparsity_weight: float = 0.01) -> dict:
-    """model.py:304-322: hidden = relu(enc(x)); recon = dec(hidden); loss = mse + w * mean|hidden|."""
+def fp8_e4m3_round(a: np.ndarray) -> np.ndarray:
+    """Nearest OCP e4m3fn value, ties to even (what v_cvt_pk_fp8_f32 does on gfx950: profiles/tools/probe_fp8.hip).
+    3 mantissa bits, exponents 2^-6 .. 2^8, subnormal spacing 2^-9, largest finite 448; callers scale into range."""
+    a = np.asarray(a, dtype=F64)
+    mag = np.abs(a)
+    e = np.floor(np.log2(np.maximum(mag, 2.0 ** -20)))
+    e = np.clip(e, -6, 8)
+    step = 2.0 ** (e - 3)
+    q = np.rint(mag / step) * step  # np.rint rounds half to even
+    assert (q <= 448).all(), "fp8_e4m3_round: value outside the finite range"
+    return (np.sign(a) * q).astype(F32)
+
+
+def fp8_quant_rows(v: np.ndarray):
+    """Per-row e4m3 quantisation as wsae_relu.hip's quant_rows_kernel: q = e4m3(v * (448 / amax)), scale = amax / 448,
+    all in fp32 arithmetic.  Returns (q as float32 values, scale [rows])."""
+    v = np.asarray(v, dtype=F32)
+    amax = np.abs(v).max(axis=1).astype(F32)
+    inv = np.where(amax > 0, F32(448.0) / np.where(amax > 0, amax, F32(1)), F32(1)).astype(F32)
+    scale = np.where(amax > 0, amax / F32(448.0), F32(1)).astype(F32)
+    return fp8_e4m3_round((v * inv[:, None]).astype(F32)), scale
+
+
+def relu_forward(W_e, b_e, W_d, b_d, x, sparsity_weight: float = 0.01, mode: str = "fp32") -> dict:
+    """model.py:304-322: hidden = relu(enc(x)); recon = dec(hidden); loss = mse + w * mean|hidden|.
+
+    ``mode="fp8"`` mirrors the device's fp8 forward (BASELINE.json configs[4]; wsae_ctx_set_relu_fp8): both GEMMs on
+    e4m3 copies of their operands - x and bf16(hidden) per batch row, bf16(W_e) per feature row, bf16(W_d) per output
+    row - with fp32 accumulation and ``row scale * column scale`` applied to the accumulator before the bias."""
     x = np.asarray(x, dtype=F32)
-    pre = (x.astype(F64) @ W_e.astype(F64).T + b_e.astype(F64)).astype(F32)
-    hidden = np.maximum(pre, 0).astype(F32)
-    recon = (hidden.astype(F64) @ W_d.astype(F64).T + b_d.astype(F64)).astype(F32)
+    if mode == "fp8":
+        xq, sx = fp8_quant_rows(x)
+        wq, sw = fp8_quant_rows(bf16_round(W_e))
+        pre = ((xq.astype(F64) @ wq.astype(F64).T).astype(F32) * (sx[:, None] * sw[None, :]).astype(F32) + b_e).astype(F32)
+        hidden = np.maximum(pre, 0).astype(F32)
+        hq, sh = fp8_quant_rows(bf16_round(hidden))
+        dq, sd = fp8_quant_rows(bf16_round(W_d))
+        recon = ((hq.astype(F64) @ dq.astype(F64).T).astype(F32) * (sh[:, None] * sd[None, :]).astype(F32) + b_d).astype(F32)
+    else:
+        pre = (x.astype(F64) @ W_e.astype(F64).T + b_e.astype(F64)).astype(F32)
+        hidden = np.maximum(pre, 0).astype(F32)
+        recon = (hidden.astype(F64) @ W_d.astype(F64).T + b_d.astype(F64)).astype(F32)
     resid = recon.astype(F64) - x.astype(F64)
     mse = F32(np.mean(resid * resid))
     l1 = F32(np.mean(np.abs(hidden.astype(F64))))

@@ -208,3 +208,17 @@ class TestReLUG8:
         b = O.relu_backward(*args, f, sparsity_weight=0.01)
         for n, key in (("W_e", "dW_e"), ("b_e", "db_e"), ("W_d", "dW_d"), ("b_d", "db_d")):
             assert rel(b[n], g[key]) < 2e-5, n
+
+
+def test_fp8_e4m3_rounding_equals_torch_float8():
+    """The oracle's ``"fp8"`` mode (ReLU forward, BASELINE.json configs[4]) rounds like ``torch.float8_e4m3fn``."""
+    import torch
+    rng = np.random.default_rng(0)
+    for scale in (100.0, 1.0, 0.01):
+        v = np.clip(rng.normal(size=200000) * scale, -448, 448).astype(np.float32)
+        want = torch.from_numpy(v).to(torch.float8_e4m3fn).float().numpy()
+        assert np.array_equal(O.fp8_e4m3_round(v), want)
+    ties = np.array([17.0, 19.0, 1.0625, 1.1875, 0.0009765625, 448.0, 463.9, -17.0], np.float32)
+    assert np.array_equal(O.fp8_e4m3_round(ties), torch.from_numpy(ties).to(torch.float8_e4m3fn).float().numpy())
+    q, s = O.fp8_quant_rows(np.array([[1.0, -3.0, 0.5], [0.0, 0.0, 0.0]], np.float32))
+    assert q[0, 1] == -448.0 and s[0] == np.float32(3.0) / np.float32(448.0) and s[1] == 1.0 and (q[1] == 0).all()

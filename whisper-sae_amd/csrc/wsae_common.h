@@ -102,6 +102,7 @@ struct wsae_ctx {
     int32_t* counters;    // small int scratch (fallback rows, resample cursors; [16..) = arrival tickets, 8-byte aligned)
     int32_t* dead_list;   // [H] compacted dead feature indices (resample)
     int32_t* row_order;   // [maxB] rows sorted by error (resample)
+    int relu_fp8;         // 1: the ReLU SAE's two forward GEMMs run on fp8 e4m3 operands (wsae_ctx_set_relu_fp8)
     void* relu_ws;        // ReLU-SAE workspace (wsae_relu.hip), allocated by wsae_ctx_reserve_relu
     float* fired;         // caller-owned [H] indicator buffer for the DDP dead-feature clock, or null
     int n_dec_blocks;     // blocks used by the last decode launch (partials to reduce)
@@ -195,6 +196,7 @@ __device__ __forceinline__ float load_act(const void* p, int64_t i) {
 #endif  // __HIPCC__
 
 // internal (wsae_encode.hip): stage the batch (xb, xT) and run the dense encoder GEMM into pre [B][H]
+int wsae_internal_stage(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, hipStream_t st);
 int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,
                                  int B, float* pre, int64_t* step_count, int direct, hipStream_t st);
 // internal (wsae_encode.hip): the standalone TopK launch over ctx->pre; whether the strip-guided form applies
@@ -209,5 +211,8 @@ int wsae_internal_decode_mfma(wsae_ctx* c, const float* params, const void* x, i
                               int want_g32, int64_t* last_activated, const int64_t* step_count, wsae_stats* stats,
                               hipStream_t st);
 // internal (wsae_encode.hip): the persistent LDS-DMA NT GEMM for other dense contractions; false = shape not supported
+bool wsae_internal_gemm256d_fp8(wsae_ctx* c, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* rscale,
+                                const float* cscale, const float* bias, float* C, int64_t ldc, int M, int N, int K,
+                                hipStream_t st);
 bool wsae_internal_gemm256d(wsae_ctx* c, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias, float* C,
                             int64_t ldc, int M, int N, int K, int nsplit, int64_t cz, hipStream_t st);

@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(512)
 encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restrict__ W, int64_t ldb,
                        const float* __restrict__ bias, float* __restrict__ pre, int64_t ldp, int B, int H, int D, int ntn,
                        int ntiles_mn, int nsplit, int64_t cz, float* __restrict__ smax, const int32_t* __restrict__ arows,
-                       int64_t* __restrict__ step_count) {
+                       int64_t* __restrict__ step_count, const float* __restrict__ rscale = nullptr,
+                       const float* __restrict__ cscale = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = SWZ_ROW_BYTES / (int)sizeof(T);
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -179,6 +180,9 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
         const int hcol = n0 + wn * 64 + pc;
         float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias && z == 0 && hcol < H) bv4 = *(const float4*)(bias + hcol);
+        // quantised operands (fp8): C = rscale[m] * cscale[n] * acc (+ bias)
+        float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (cscale && hcol < H) cs4 = *(const float4*)(cscale + hcol);
         float* Cz = pre + (int64_t)z * cz;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
@@ -193,6 +197,10 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
                 const int rl = pr + 4 * i;
                 const int b = m0 + wm * 128 + mi * 32 + rl;
                 float4 v = *(const float4*)(patch + rl * PS + pc);
+                if (rscale) {
+                    const float rs = rscale[min(b, B - 1)];
+                    v.x *= rs * cs4.x; v.y *= rs * cs4.y; v.z *= rs * cs4.z; v.w *= rs * cs4.w;
+                }
                 v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
                 if (b < B && hcol < H) *(float4*)(Cz + (int64_t)b * ldp + hcol) = v;
                 if (smax) {
@@ -493,10 +501,31 @@ static bool gemm256d_try(wsae_ctx* c, const void* A, int64_t lda, const void* Bt
     return true;
 }
 
+// fp8 e4m3 operands with a dequantisation scale per row of A and per row of Bt (the ReLU SAE's fp8 forward)
+bool wsae_internal_gemm256d_fp8(wsae_ctx* c, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* rscale,
+                                const float* cscale, const float* bias, float* C, int64_t ldc, int M, int N, int K,
+                                hipStream_t st) {
+    constexpr int KT = SWZ_ROW_BYTES;  // 128 one-byte elements per slab
+    if (M < 512 || N < 128 || N % 4 || K % (2 * KT) || lda % 16 || ldb % 16 || ldc % 4 || !rscale || !cscale) return false;
+    const int ntn = ceil_div(N, 256), ntiles_mn = ntn * ceil_div(M, 256);
+    encode_gemm256d_kernel<fp8_t><<<min(ntiles_mn, c->cus), 512, G256D_LDS, st>>>((const fp8_t*)A, lda, (const fp8_t*)Bt, ldb, bias, C, ldc,
+                                                                                 M, N, K, ntn, ntiles_mn, 1, 0, nullptr, nullptr,
+                                                                                 nullptr, rscale, cscale);
+    return true;
+}
+
 bool wsae_internal_gemm256d(wsae_ctx* c, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias, float* C,
                             int64_t ldc, int M, int N, int K, int nsplit, int64_t cz, hipStream_t st) {
     return c->prec == WSAE_PREC_BF16 ? gemm256d_try<bf16_t>(c, A, lda, Bt, ldb, bias, C, ldc, M, N, K, nsplit, cz, st)
                                      : gemm256d_try<float>(c, A, lda, Bt, ldb, bias, C, ldc, M, N, K, nsplit, cz, st);
+}
+
+// staging alone (xb, xT): for callers that run their own encoder GEMM (the ReLU SAE's fp8 forward)
+int wsae_internal_stage(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, hipStream_t st) {
+    const int rc = ctx->prec == WSAE_PREC_BF16 ? stage_batch<bf16_t>(ctx, params, x, x_dtype, rows, B, nullptr, st)
+                                                : stage_batch<float>(ctx, params, x, x_dtype, rows, B, nullptr, st);
+    if (rc == WSAE_OK) ctx->xT_valid = 1;
+    return rc;
 }
 
 int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,

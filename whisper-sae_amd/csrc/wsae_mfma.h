@@ -375,3 +375,36 @@ struct Mfma256s<float> {
         }
     }
 };
+
+// OCP fp8 e4m3 operands (gfx950: v_mfma_f32_32x32x16_fp8_fp8, the bf16 form's rate on half the operand bytes).
+// A 128-byte image row holds 128 K elements = 8 MFMA K steps; lane l supplies A[l & 31][8 (l >> 5) + j] as byte j of a
+// 64-bit operand (profiles/tools/probe_fp8.hip), i.e. half (l >> 5) of 16-byte chunk kk.
+struct fp8_t {
+    uint8_t bits;
+};
+
+template <>
+struct Mfma256s<fp8_t> {
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
+                                                f32x16 (&acc)[4][2]) {
+        const int r = lane & 31, h = lane >> 5;
+        const int sw = (r >> 1) & 7;
+        const char* ap = As + (a_row0 + r) * SWZ_ROW_BYTES + 8 * h;
+        const char* bp = Bs + (b_row0 + r) * SWZ_ROW_BYTES + 8 * h;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int co = (kk ^ sw) << 4;
+            long a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *(const long*)(ap + i * 32 * SWZ_ROW_BYTES + co);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b[i] = *(const long*)(bp + i * 32 * SWZ_ROW_BYTES + co);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+

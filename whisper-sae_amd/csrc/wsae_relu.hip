@@ -25,6 +25,15 @@ struct ReluWs {
     float* colpart; // [ceil(maxB/64)][H]  per-tile column sums of dpre (db_e)
     float* scal;    // [4]         sparsity, mse
     int nblk;
+    // fp8 forward (wsae_ctx_set_relu_fp8): e4m3 copies of the two GEMMs' operands and their per-row dequantisation scales
+    uint8_t* xq;    // [maxB][D]
+    uint8_t* weq;   // [H][D]
+    uint8_t* hidq;  // [maxB][H]
+    uint8_t* wdq;   // [D][H]
+    float* sx;      // [maxB]
+    float* swe;     // [H]
+    float* sh;      // [maxB]
+    float* swd;     // [D]
 };
 
 int reserve_ws(wsae_ctx* c) {
@@ -51,7 +60,11 @@ int reserve_ws(wsae_ctx* c) {
     const size_t o4 = o3 + up(D * H * es);
     const size_t o5 = o4 + up(3 * nblk * 4);
     const size_t o6 = o5 + up(nb * H * 4);
-    const size_t total = o6 + 256;
+    const size_t q0 = o6 + 256;
+    const size_t maxB = c->maxB;
+    const size_t q1 = q0 + up(maxB * D), q2 = q1 + up(H * D), q3 = q2 + up(maxB * H), q4 = q3 + up(D * H);
+    const size_t q5 = q4 + up(maxB * 4), q6 = q5 + up(H * 4), q7 = q6 + up(maxB * 4);
+    const size_t total = q7 + up(D * 4);
     char* base = nullptr;
     if (hipMalloc((void**)&base, total) != hipSuccess) {
         wsae_set_error("wsae_relu: cannot allocate the %zu-byte ReLU workspace", total);
@@ -61,6 +74,8 @@ int reserve_ws(wsae_ctx* c) {
     h.hid = base + o0; h.hidT = base + o1; h.dpreT = base + o2; h.wd_nt = base + o3;
     h.part = (float*)(base + o4); h.colpart = (float*)(base + o5); h.scal = (float*)(base + o6);
     h.nblk = (int)nblk;
+    h.xq = (uint8_t*)base + q0; h.weq = (uint8_t*)base + q1; h.hidq = (uint8_t*)base + q2; h.wdq = (uint8_t*)base + q3;
+    h.sx = (float*)(base + q4); h.swe = (float*)(base + q5); h.sh = (float*)(base + q6); h.swd = (float*)(base + q7);
     if (hipMemset(base, 0, total) != hipSuccess || hipMemcpy(base, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(base);
         wsae_set_error("wsae_relu: workspace initialisation failed");
@@ -85,8 +100,17 @@ ReluWs host_ws(wsae_ctx* c) {  // the descriptor is also kept at the head of the
     h.wd_nt = base + o; o += up(D * H * es);
     h.part = (float*)(base + o); o += up(3 * nblk * 4);
     h.colpart = (float*)(base + o); o += up(nb * H * 4);
-    h.scal = (float*)(base + o);
+    h.scal = (float*)(base + o); o += 256;
     h.nblk = (int)nblk;
+    const size_t maxB = c->maxB;
+    h.xq = (uint8_t*)base + o; o += up(maxB * D);
+    h.weq = (uint8_t*)base + o; o += up(H * D);
+    h.hidq = (uint8_t*)base + o; o += up(maxB * H);
+    h.wdq = (uint8_t*)base + o; o += up(D * H);
+    h.sx = (float*)(base + o); o += up(maxB * 4);
+    h.swe = (float*)(base + o); o += up(H * 4);
+    h.sh = (float*)(base + o); o += up(maxB * 4);
+    h.swd = (float*)(base + o);
     return h;
 }
 
@@ -379,19 +403,83 @@ int check_dims(wsae_ctx* ctx, int B, const char* who) {
     return WSAE_OK;
 }
 
+// ---- fp8 e4m3 quantisation of a row-major matrix, one scale per row --------------------------------------
+// q[r][c] = e4m3(v[r][c] * (448 / amax_r)) (v_cvt_pk_fp8_f32: round to nearest even), scale[r] = amax_r / 448 (1 for an
+// all-zero row).  One wave per row, two passes (the second one from L2); 8 values -> one 8-byte store per lane.
+template <int SRC>
+__global__ void __launch_bounds__(256) quant_rows_kernel(const void* __restrict__ src, const int32_t* __restrict__ rows, int R, int C,
+                                                         uint8_t* __restrict__ q, float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int64_t sr = rows ? (int64_t)rows[r] : (int64_t)r;
+    auto load8 = [&](int c, float (&v)[8]) {
+        if (SRC == WSAE_DT_F32) {
+            const float4 a = *(const float4*)((const float*)src + sr * C + c), b = *(const float4*)((const float*)src + sr * C + c + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+            const bf16x8 a = *(const bf16x8*)((const bf16_t*)src + sr * C + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+        }
+    };
+    float amax = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        float v[8];
+        load8(c, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    }
+    amax = wave_max(amax);
+    const float inv = amax > 0.f ? 448.f / amax : 1.f;
+    if (lane == 0) scale[r] = amax > 0.f ? amax / 448.f : 1.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        float v[8];
+        load8(c, v);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+        *(int2*)(q + (int64_t)r * C + c) = make_int2(lo, hi);
+    }
+}
+
+static void quant_rows(hipStream_t st, const void* src, int dtype, const int32_t* rows, int R, int C, uint8_t* q, float* scale) {
+    if (dtype == WSAE_DT_F32) quant_rows_kernel<WSAE_DT_F32><<<ceil_div(R, 4), 256, 0, st>>>(src, rows, R, C, q, scale);
+    else quant_rows_kernel<WSAE_DT_BF16><<<ceil_div(R, 4), 256, 0, st>>>(src, rows, R, C, q, scale);
+}
+
 template <typename T>
 int forward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, float weight,
               float* hidden, float* recon, wsae_stats* stats, float* sparsity_out, hipStream_t st) {
     const int D = ctx->D, H = ctx->H;
     const int ldT = (B + 127) / 128 * 128;
     const ReluWs ws = host_ws(ctx);
-    int rc = wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, nullptr, 0, st);  // pre = x W_e^T + b_e
+    // fp8 forward (BF16 mode + wsae_ctx_set_relu_fp8): the two forward GEMMs take e4m3 copies of their operands, one
+    // dequantisation scale per row; everything else (hidden, residual, loss, the whole backward) is the bf16 path's
+    const bool fp8 = sizeof(T) == 2 && ctx->relu_fp8;
+    int rc = fp8 ? wsae_internal_stage(ctx, params, x, x_dtype, rows, B, st)  // (the backward reads the staged xT)
+                 : wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, nullptr, 0, st);  // pre = x W_e^T + b_e
     if (rc) return rc;
+    if (fp8) {
+        quant_rows(st, x, x_dtype, rows, B, D, ws.xq, ws.sx);
+        quant_rows(st, ctx->We_bf16, WSAE_DT_BF16, nullptr, H, D, ws.weq, ws.swe);
+        WSAE_REQUIRE(wsae_internal_gemm256d_fp8(ctx, ws.xq, D, ws.weq, D, ws.sx, ws.swe, params + ctx->off[2], ctx->pre, H, B, H, D, st),
+                     "wsae_relu_forward: the fp8 forward needs batch >= 512, hidden_dim %% 4 == 0, input_dim %% 256 == 0 (got B %d, D %d)", B, D);
+    }
     const T* wdt = sizeof(T) == 2 ? (const T*)ctx->WdT_bf16 : (const T*)(params + ctx->off[1]);
     transpose_w_kernel<T><<<dim3(ceil_div(H, 64), ceil_div(D, 64)), 256, 0, st>>>(wdt, (T*)ws.wd_nt, H, D);
     dim3 ga(ceil_div(H, 64), ceil_div(ldT, 64));
     relu_act_kernel<T><<<ga, 256, 0, st>>>(ctx->pre, hidden, (T*)ws.hid, (T*)ws.hidT, B, H, ldT, ws.part, ws.nblk);
-    gemm_nt<T>(ctx, st, ws.hid, H, ws.wd_nt, H, params + ctx->off[3], recon, D, B, D, H, 1, 0);  // recon = hidden W_d^T + b_d
+    if (fp8) {
+        quant_rows(st, ws.hid, WSAE_DT_BF16, nullptr, B, H, ws.hidq, ws.sh);
+        quant_rows(st, ws.wd_nt, WSAE_DT_BF16, nullptr, D, H, ws.wdq, ws.swd);
+        WSAE_REQUIRE(wsae_internal_gemm256d_fp8(ctx, ws.hidq, H, ws.wdq, H, ws.sh, ws.swd, params + ctx->off[3], recon, D, B, D, H, st),
+                     "wsae_relu_forward: the fp8 forward needs input_dim >= 128 and hidden_dim %% 256 == 0 (got D %d, H %d)", D, H);
+    } else {
+        gemm_nt<T>(ctx, st, ws.hid, H, ws.wd_nt, H, params + ctx->off[3], recon, D, B, D, H, 1, 0);  // recon = hidden W_d^T + b_d
+    }
     dim3 gr(ceil_div(D, 64), ceil_div(ldT, 64));
     if (x_dtype == WSAE_DT_F32)
         resid_kernel<T, WSAE_DT_F32, false><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, 0.f, nullptr, nullptr, nullptr,
@@ -441,6 +529,13 @@ int backward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
 }
 
 }  // namespace
+
+extern "C" int wsae_ctx_set_relu_fp8(wsae_ctx* ctx, int32_t on) {
+    WSAE_REQUIRE(ctx, "wsae_ctx_set_relu_fp8: null ctx");
+    WSAE_REQUIRE(!on || ctx->prec == WSAE_PREC_BF16, "wsae_ctx_set_relu_fp8: the fp8 forward belongs to the BF16 mode");
+    ctx->relu_fp8 = on ? 1 : 0;
+    return WSAE_OK;
+}
 
 extern "C" int wsae_ctx_reserve_relu(wsae_ctx* ctx) {
     WSAE_REQUIRE(ctx, "wsae_ctx_reserve_relu: null ctx");

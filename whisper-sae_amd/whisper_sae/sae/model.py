@@ -38,11 +38,16 @@ class SAEOutput(NamedTuple):
 def _precision_code(precision: Optional[str]) -> int:
     if precision is None:
         precision = "bf16" if torch.is_autocast_enabled() else "fp32"
-    if precision in ("bf16", "amp"):
+    if precision in ("bf16", "amp", "fp8"):  # "fp8" (ReLUSAE only): BF16 mode with e4m3 operands in the two forward GEMMs
         return N.PREC_BF16
     if precision == "fp32":
         return N.PREC_FP32
-    raise ValueError(f"precision must be 'bf16', 'fp32' or None, got {precision!r}")
+    raise ValueError(f"precision must be 'bf16', 'fp32', 'fp8' (ReLUSAE) or None, got {precision!r}")
+
+
+def relu_fp8_flag(module) -> int:
+    """1 when the module asks for the fp8 forward (``ReLUSAE(precision="fp8")``, BASELINE.json configs[4])."""
+    return 1 if getattr(module, "precision", None) == "fp8" else 0
 
 
 class _TopKForward(torch.autograd.Function):
@@ -355,6 +360,7 @@ class _ReLUForward(torch.autograd.Function):
         B = x2.shape[0]
         handle = eng.prepare(prec, B, force=True)
         eng.reserve_relu(handle)
+        N.check(eng.lib.wsae_ctx_set_relu_fp8(handle, relu_fp8_flag(module)), "wsae_ctx_set_relu_fp8")
         hidden = torch.empty(B, eng.H, dtype=torch.float32, device=eng.device)
         recon = torch.empty(B, eng.D, dtype=torch.float32, device=eng.device)
         sparsity = torch.empty((), dtype=torch.float32, device=eng.device)
@@ -379,6 +385,7 @@ class _ReLUForward(torch.autograd.Function):
         x2, hidden, recon = ctx.saved_tensors
         handle = eng.prepare(prec, B, force=True)
         eng.reserve_relu(handle)
+        N.check(eng.lib.wsae_ctx_set_relu_fp8(handle, relu_fp8_flag(module)), "wsae_ctx_set_relu_fp8")
         pk, xd, st = eng.pack.data_ptr(), _dtype_code(x2), eng.stream()
         w = float(module.sparsity_weight)
         if eng.generation != ctx.gen:  # another forward reused the ctx workspace since: rebuild xT / hidden^T for this batch

@@ -33,6 +33,7 @@ from .. import _native as N
 from ..config import TrainingConfig
 from ..distributed import barrier, rank_and_world, sync_gradients, world
 from .engine import _dtype_code, require_device_tensor
+from .model import relu_fp8_flag
 from .optim import FusedAdamW
 
 
@@ -264,6 +265,10 @@ class SAETrainer:
         """ReLU + L1 step (reference ReLUSAE under training.py:161-217; no dead-feature bookkeeping)."""
         lib, st = eng.lib, eng.stream()
         eng.reserve_relu(handle)
+        fp8 = relu_fp8_flag(model)
+        if fp8 and prec != N.PREC_BF16:
+            raise N.WsaeError("ReLUSAE(precision='fp8') trains with TrainingConfig.use_amp = True (the fp8 forward belongs to the bf16 mode)")
+        N.check(lib.wsae_ctx_set_relu_fp8(handle, fp8), "wsae_ctx_set_relu_fp8")
         w = eng.relu_work(B)
         pk, xd, rp = eng.pack.data_ptr(), _dtype_code(x), N.ptr(rows)
         chunk, slot = self._records.next(eng.device)
