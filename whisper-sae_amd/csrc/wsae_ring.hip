@@ -15,6 +15,12 @@ struct wsae_ring {
 extern "C" int wsae_ring_create(int32_t device, int64_t capacity_rows, int32_t dim, int32_t dtype, wsae_ring** out) {
     WSAE_REQUIRE(out && capacity_rows >= 1 && dim >= 1, "wsae_ring_create: bad argument");
     WSAE_REQUIRE(dtype == WSAE_DT_F32 || dtype == WSAE_DT_BF16, "wsae_ring_create: unknown dtype %d", dtype);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    struct Restore {  // the caller's current device comes back on every return path
+        int d;
+        ~Restore() { if (d >= 0) (void)hipSetDevice(d); }
+    } restore{prev};
     WSAE_HIP_CHECK(hipSetDevice(device));
     wsae_ring* r = new (std::nothrow) wsae_ring();
     if (!r) {
