@@ -156,6 +156,13 @@ class TestShapesAgainstOracle:
         # rounding boundary lands on the other side when the fp32 sums are taken in a different order (oracle: numpy,
         # kernel: MFMA / wave order), i.e. single entries differ by one bf16 ulp (0.4 %) - hence 2e-3 of the max
         (768, 12288, 64, 192, "bf16", "amp", 2e-3),
+        # every width / k class of the MFMA decode kernel (D / 128 column pieces x one or two 32-row gather groups)
+        (128, 1024, 16, 300, "bf16", "amp", 2e-3),
+        (256, 2048, 32, 300, "bf16", "amp", 2e-3),
+        (384, 4096, 64, 200, "bf16", "amp", 2e-3),
+        (768, 3072, 32, 200, "bf16", "amp", 2e-3),
+        (1280, 5120, 32, 200, "bf16", "amp", 2e-3),
+        (1280, 5120, 64, 200, "bf16", "amp", 2e-3),
     ])
     def test_forward_backward(self, device, D, H, K, B, precision, mode, tol):
         m, st = build(D, H, K, 21, True, 0.1, 1000, device, precision)
@@ -435,7 +442,7 @@ class TestDdpClock:
         fired_other = torch.from_numpy(((other["hidden"] > 0).any(axis=0)).astype(np.float32)).to(device)
         seen = {}
 
-        def fake_all_reduce(flat):
+        def fake_all_reduce(flat, exchange_dtype=torch.float32):
             P = flat.numel() - H
             seen["local"] = flat[P:].clone()
             flat[P:] += fired_other     # SUM over the two ranks
