@@ -76,8 +76,8 @@ def main() -> None:
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the median is reported")
-    ap.add_argument("--grad-exchange", choices=("fp32", "bf16"), default="fp32",
-                    help="N > 1: dtype of the gradient all-reduce (default fp32, the exact data-parallel gradient)")
+    ap.add_argument("--grad-exchange", choices=("auto", "fp32", "bf16"), default="auto",
+                    help="N > 1: dtype of the gradient all-reduce (auto = bf16 in the bf16 mode, fp32 in the fp32 mode)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel (adds event overhead)")
     ap.add_argument("--dims", type=int, nargs=3, metavar=("D", "H", "K"), default=None,
                     help="informational: other SAE dimensions (e.g. 768 12288 64 = BASELINE.json configs[3]); no roofline object")
@@ -211,7 +211,7 @@ def main() -> None:
                                    f" (configs[2]: DDP x{world}, RCCL grad all-reduce)"),
                        "batch_per_gpu": B, "global_batch": world * B, "ring_rows_per_gpu": args.ring_rows,
                        "lr": 1e-4, "clip": 1.0, "parallelism": f"dp{world}",
-                       **({"grad_exchange": args.grad_exchange} if world > 1 else {})},
+                       **({"grad_exchange": trainer.grad_exchange} if world > 1 else {})},
             "roofline": roof,
             "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS,
             "final_loss": last.loss if last is not None else None,

@@ -124,7 +124,8 @@ def test_two_ranks_equal_the_single_process_step(device, tmp_path, use_amp):
     for key in KEYS:
         diff = np.abs(one[key].astype(np.float64) - r0[key].astype(np.float64))
         # AdamW's early steps move an entry by ~lr * sign(g): entries with |g| at rounding level may go the other way
-        assert np.mean(diff < 0.05 * LR) > 0.995, key
+        # (bf16 mode: the two ranks' gradients also meet on a bf16 wire, TrainingConfig.grad_exchange_dtype = "auto")
+        assert np.mean(diff < 0.05 * LR) > (0.98 if use_amp else 0.995), key
         assert diff.max() < 2.5 * LR * STEPS, key
 
     # ---- step 1 against the oracle's own data-parallel restatement ----

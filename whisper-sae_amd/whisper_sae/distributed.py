@@ -7,8 +7,8 @@ concatenated N*B batch.  One process per GPU; ``torch.distributed`` backend ``"n
 ROCm (xGMI inside a node); ``"gloo"`` runs the same code on CPU tensors for tests.
 
 Per step there is ONE collective: ``all_reduce(SUM)`` of the flat buffer ``[gradient pack | fired]``
-(9.45 MB + 12 KB fp32 at 384->3072; the 1/world factor is folded into the fused optimizer kernel as
-``grad_scale``).  ``fired[f]`` is 1.0 on the ranks where feature f fired in this step; its sum tells
+(9.45 MB + 12 KB at 384->3072 as fp32 - the fp32 mode - or half of that as bf16 - the bf16 mode's default; the
+1/world factor is folded into the fused optimizer kernel as ``grad_scale``).  ``fired[f]`` is 1.0 on the ranks where feature f fired in this step; its sum tells
 every rank which ``feature_last_activated`` entries to stamp with the current step, which equals an
 ``all_reduce(MAX)`` of the clocks (clocks that agreed before the step either all advance to the step or
 all stay) without a second, latency-bound collective.
@@ -30,7 +30,8 @@ def world():
 def sync_gradients(flat: torch.Tensor, exchange_dtype: torch.dtype = torch.float32) -> float:
     """Sum ``flat`` (gradient pack, optionally followed by the fired indicators) over all ranks, in place.
 
-    ``exchange_dtype=torch.bfloat16`` (``TrainingConfig.grad_exchange_dtype = "bf16"``, off by default) sends the
+    ``exchange_dtype=torch.bfloat16`` (``TrainingConfig.grad_exchange_dtype``: the default ``"auto"`` picks it in the
+    bf16 mode, where the weight-gradient GEMMs already take bf16-rounded ``dpre`` / ``g`` / ``hidden``) sends the
     buffer as bf16 - half the bytes over xGMI, what PyTorch DDP's ``bf16_compress_hook`` does: every rank rounds its
     gradients to bf16, RCCL sums in bf16, the sum is widened back.  The fired indicators (sums of at most
     ``world_size`` ones) survive exactly; the gradients carry a relative error of about 2^-8 per addend.

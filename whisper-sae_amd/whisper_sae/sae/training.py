@@ -139,7 +139,11 @@ class SAETrainer:
 
         on_gpu = str(device).startswith("cuda")
         self.use_amp = bool(config.use_amp and on_gpu)  # bf16 MFMA contractions when set, fp32 MFMA otherwise
-        self._exchange_dtype = torch.bfloat16 if getattr(config, "grad_exchange_dtype", "fp32") == "bf16" else torch.float32
+        exch = getattr(config, "grad_exchange_dtype", "auto")
+        if exch == "auto":
+            exch = "bf16" if self.use_amp else "fp32"
+        self.grad_exchange = exch  # resolved: what sync_gradients puts on the wire under torch.distributed
+        self._exchange_dtype = torch.bfloat16 if exch == "bf16" else torch.float32
         self.scaler = torch.amp.GradScaler("cuda", enabled=False)  # bf16 needs no loss scaling
 
         self.global_step = 0
