@@ -192,6 +192,10 @@ int wsae_input_grad(wsae_ctx* ctx, const float* params, const int32_t* idx, cons
  * last_activated (nullable) / step_count / dead_threshold: when given, stats->dead_count and
  *   stats->dead_ratio are written (get_dead_feature_ratio() of training.py:212).
  * All four buffers use the flat pack layout. */
+/* Data parallel with a bf16 wire: widen the summed buffer [gradient pack | fired] (n_total bf16 elements, a multiple
+ * of 8) into the fp32 buffer wsae_adamw_step reads and leave the gradient part's squared-norm partials in the ctx, so
+ * that the following wsae_adamw_step(norm_from_wgrad = 1, grad_scale = 1 / world) needs no norm pass of its own. */
+int wsae_grads_unpack_wire(wsae_ctx* ctx, const void* wire_bf16, int64_t n_total, float* grads_ext, void* stream);
 int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads, float* exp_avg,
                     float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step, float max_norm, float grad_scale,

@@ -442,11 +442,13 @@ class TestDdpClock:
         fired_other = torch.from_numpy(((other["hidden"] > 0).any(axis=0)).astype(np.float32)).to(device)
         seen = {}
 
-        def fake_all_reduce(flat, exchange_dtype=torch.float32):
+        def fake_all_reduce(flat, exchange_dtype=torch.float32, unpack=None):
             P = flat.numel() - H
             seen["local"] = flat[P:].clone()
             flat[P:] += fired_other     # SUM over the two ranks
             flat[:P] *= 2.0             # (both ranks hold this rank's gradients: sum = 2x, scale 1/2 below)
+            if unpack is not None:      # bf16 wire: the trainer widens the summed buffer itself (and takes the norm)
+                unpack(flat.to(exchange_dtype))
             return 0.5
 
         monkeypatch.setattr(T, "world", lambda: (None, 2))

@@ -19,6 +19,43 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// ---- data parallel, bf16 wire (whisper_sae/distributed.py): the summed bf16 buffer [gradient pack P | fired H] is
+// widened back into the fp32 buffer the optimizer reads and, in the same pass, the gradient part's sum of squares is
+// left in the norm partials - the separate 9.45 MB norm pass of the DDP step is gone (wsae_adamw_step with
+// norm_from_wgrad = 1 takes them).  8 values per thread and trip; fixed reduction order.
+__global__ void __launch_bounds__(256) wire_unpack_kernel(const bf16_t* __restrict__ wire, int64_t n8, int64_t p8,
+                                                          float* __restrict__ out, float* __restrict__ part) {
+    __shared__ float red[8];
+    float a = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 v = ((const bf16x8*)wire)[i];
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+        ((float4*)out)[2 * i] = make_float4(f[0], f[1], f[2], f[3]);
+        ((float4*)out)[2 * i + 1] = make_float4(f[4], f[5], f[6], f[7]);
+        if (i < p8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(f[e], f[e], a);
+        }
+    }
+    const float t = block_sum(a, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+extern "C" int wsae_grads_unpack_wire(wsae_ctx* ctx, const void* wire_bf16, int64_t n_total, float* grads_ext, void* stream) {
+    WSAE_REQUIRE(ctx && wire_bf16 && grads_ext, "wsae_grads_unpack_wire: null argument");
+    WSAE_REQUIRE(n_total >= ctx->P && n_total % 8 == 0 && ctx->P % 8 == 0,
+                 "wsae_grads_unpack_wire: buffer of %lld elements (pack %lld): both must be multiples of 8", (long long)n_total,
+                 (long long)ctx->P);
+    const int64_t n8 = n_total / 8;
+    const int nparts = (int)min((int64_t)WSAE_MAX_PARTIALS, ceil_div64(n8, 256));
+    wire_unpack_kernel<<<nparts, 256, 0, (hipStream_t)stream>>>((const bf16_t*)wire_bf16, n8, ctx->P / 8, grads_ext, ctx->part_sq);
+    WSAE_LAUNCH_CHECK();
+    ctx->n_sq_parts = nparts;
+    return WSAE_OK;
+}
+
 // ---- per-feature-row maintenance, one wave per feature row h ---------------------------------------
 //   NORMALIZE: W_dT[h,:] /= max(||W_dT[h,:]||_2, 1e-12)   == F.normalize(decoder.weight, dim=0), column h
 //   SHADOW   : bf16 shadows of W_e[h,:] and W_dT[h,:], folded bias c[h] = b_e[h] - bf16(W_e)[h,:] . b_pre

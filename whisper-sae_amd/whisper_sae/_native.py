@@ -64,6 +64,7 @@ SIGNATURES = {
     "wsae_weight_grads": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     "wsae_last_residual_grad": (C.c_int, [_p, _i32, _p, _p]),
     "wsae_input_grad": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i32, _p]),
+    "wsae_grads_unpack_wire": (C.c_int, [_p, _p, _i64, _p, _p]),
     "wsae_adamw_step": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _i32,
                                   _p, _p, _i64, _p, _p]),
     "wsae_normalize_decoder": (C.c_int, [_p, _p, _p]),

@@ -27,7 +27,7 @@ def world():
     return None, 1
 
 
-def sync_gradients(flat: torch.Tensor, exchange_dtype: torch.dtype = torch.float32) -> float:
+def sync_gradients(flat: torch.Tensor, exchange_dtype: torch.dtype = torch.float32, unpack=None) -> float:
     """Sum ``flat`` (gradient pack, optionally followed by the fired indicators) over all ranks, in place.
 
     ``exchange_dtype=torch.bfloat16`` (``TrainingConfig.grad_exchange_dtype``: the default ``"auto"`` picks it in the
@@ -35,6 +35,9 @@ def sync_gradients(flat: torch.Tensor, exchange_dtype: torch.dtype = torch.float
     buffer as bf16 - half the bytes over xGMI, what PyTorch DDP's ``bf16_compress_hook`` does: every rank rounds its
     gradients to bf16, RCCL sums in bf16, the sum is widened back.  The fired indicators (sums of at most
     ``world_size`` ones) survive exactly; the gradients carry a relative error of about 2^-8 per addend.
+
+    ``unpack`` (optional, bf16 wire only): called with the summed wire tensor instead of ``flat.copy_(wire)`` - the
+    trainer passes ``wsae_grads_unpack_wire``, which widens into ``flat`` and leaves the norm partials in one pass.
 
     Returns the factor the caller must scale the summed gradients by (``1 / world_size``).
     """
@@ -46,7 +49,10 @@ def sync_gradients(flat: torch.Tensor, exchange_dtype: torch.dtype = torch.float
     else:
         wire = flat.to(exchange_dtype)
         dist.all_reduce(wire, op=dist.ReduceOp.SUM)
-        flat.copy_(wire)
+        if unpack is not None:
+            unpack(wire)
+        else:
+            flat.copy_(wire)
     return 1.0 / n
 
 

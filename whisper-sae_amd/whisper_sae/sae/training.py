@@ -251,9 +251,21 @@ class SAETrainer:
         eng.generation += 1
         # data parallel: ONE RCCL all-reduce of [gradients | fired indicators]; the optimizer kernel applies
         # 1/world and stamps the dead-feature clock of every feature that fired on any rank
-        grad_scale = sync_gradients(opt.grads_ext, self._exchange_dtype) if ddp else 1.0
+        fused_norm = True  # the norm partials come with the gradients: from wsae_weight_grads, or from the wire unpack
+        if ddp:
+            unpack = None
+            if self._exchange_dtype == torch.bfloat16 and opt.grads_ext.numel() % 8 == 0 and eng.P % 8 == 0:
+                def unpack(wire, _h=handle, _g=opt.grads_ext):
+                    N.check(lib.wsae_grads_unpack_wire(_h, wire.data_ptr(), wire.numel(), _g.data_ptr(), eng.stream()),
+                            "wsae_grads_unpack_wire")
+                    wire.record_stream(torch.cuda.current_stream(eng.device))
+            else:
+                fused_norm = False  # the norm has to be taken after the all-reduce: one more pass over the gradients
+            grad_scale = sync_gradients(opt.grads_ext, self._exchange_dtype, unpack)
+        else:
+            grad_scale = 1.0
         opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=grad_scale,
-                 normalize_decoder=True, batch=B, norm_from_wgrad=(grad_scale == 1.0), dead_scan=True,
+                 normalize_decoder=True, batch=B, norm_from_wgrad=fused_norm, dead_scan=True,
                  stats_ptr=stats)
         self._token = model.param_token()
         if self.scheduler is not None:
