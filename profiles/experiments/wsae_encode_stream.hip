@@ -4,7 +4,8 @@
 // At K = D = 384 a 256 x 256 tile is only six K slabs deep: the persistent tile kernel (encode_gemm256d_kernel) spends
 // its time waiting for the next slab's DMA behind a barrier and transposing its accumulators through LDS (56 us without
 // its 201 MB store, 15 us at the MFMA rate).  This kernel turns the loop round:
-//   * a workgroup owns 128 batch rows x one part of the features; each of its 4 waves keeps ITS 32 rows of x in
+//   * a workgroup owns 256 batch rows x one part of the features (one workgroup per CU: its 8 waves share every W_e slab,
+//     so a slab crosses the CU's vector-memory path once per 256 rows); each wave keeps ITS 32 rows of x in
 //     registers as MFMA A fragments for the whole kernel (96 VGPRs at D = 384) - x is read once, in whole 128-byte lines,
 //     and turned into the fragment layout through a ring slot;
 //   * W_e streams through a 3-deep LDS ring in 32-feature slabs (32 x D bf16, LDS-DMA, XOR swizzle on the source
@@ -25,7 +26,8 @@
 
 #include <type_traits>
 
-#define ES_ROWS 128
+#define ES_ROWS 256
+#define ES_WAVES 8
 #define ES_RING 3
 
 namespace {
@@ -66,14 +68,15 @@ __device__ __forceinline__ void glds16s(const void* base, uint32_t voff, uint32_
 }
 
 template <int D>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(64 * ES_WAVES, 1)
 encode_stream_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ rows, const bf16_t* __restrict__ W,
                      const float* __restrict__ bias, int B, int H, int NQ, int SP, float* __restrict__ pre,
                      float* __restrict__ smax, int64_t* __restrict__ step_count) {
     constexpr int KS = D / 16;             // MFMA K steps per slab
     constexpr int CPR = D / 8;             // 16-byte chunks per row of a slab
     constexpr int SLAB = 32 * D * 2;       // bytes of one 32-row slab
-    constexpr int PW = D / 64;             // LDS-DMA instructions per wave and slab (D / 16 per slab)
+    constexpr int PW = D / 16 / ES_WAVES;  // LDS-DMA instructions per wave and slab (D / 16 per slab)
+    constexpr int XP = D / 64;             // 128-byte column blocks of an x row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the DMA's LDS addresses stay in SGPRs
@@ -102,24 +105,24 @@ encode_stream_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ r
     bf16x8 xf[KS];
     {
         const int r8 = lane >> 3, c8 = lane & 7;
-        bf16x8 xq[4][PW];
+        bf16x8 xq[4][XP];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int rr = row0 + r8 + 8 * it;  // (< B: the launcher takes whole row tiles only)
             const bf16_t* xr = x + (rows ? (int64_t)rows[rr] : (int64_t)rr) * D + c8 * 8;
 #pragma unroll
-            for (int jj = 0; jj < PW; ++jj) xq[it][jj] = *(const bf16x8*)(xr + jj * 64);
+            for (int jj = 0; jj < XP; ++jj) xq[it][jj] = *(const bf16x8*)(xr + jj * 64);
         }
-        for (int i = tid; i < SP * 32; i += 256) bias_s[i] = bias[part * SP * 32 + i];
+        for (int i = tid; i < SP * 32; i += 64 * ES_WAVES) bias_s[i] = bias[part * SP * 32 + i];
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            if ((wave < 3) == (round == 0)) {
+        for (int round = 0; round < (ES_WAVES + 2) / 3; ++round) {
+            if (wave / 3 == round) {
                 char* slot = smem + (wave % 3) * SLAB;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int r = r8 + 8 * it;
 #pragma unroll
-                    for (int jj = 0; jj < PW; ++jj) {
+                    for (int jj = 0; jj < XP; ++jj) {
                         const int c = jj * 8 + c8;
                         *(bf16x8*)(slot + (r * CPR + ((c & ~15) | ((c ^ r) & 15))) * 16) = xq[it][jj];
                     }
@@ -142,7 +145,7 @@ encode_stream_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ r
     uint32_t dma_off[PW];
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
-        const int p = 64 * (wave + 4 * j) + lane;
+        const int p = 64 * (wave + ES_WAVES * j) + lane;
         const int r = p / CPR, cpos = p % CPR;
         const int c = (cpos & ~15) | ((cpos ^ r) & 15);
         dma_off[j] = (uint32_t)(r * D * 2 + c * 16);
@@ -152,7 +155,7 @@ encode_stream_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ r
         const char* wb = wpart + (int64_t)s * SLAB;
         const uint32_t slot = smem_lds + (uint32_t)(s % ES_RING) * SLAB;
 #pragma unroll
-        for (int j = 0; j < PW; ++j) glds16s(wb, dma_off[j], slot + (uint32_t)(wave + 4 * j) * 1024u);
+        for (int j = 0; j < PW; ++j) glds16s(wb, dma_off[j], slot + (uint32_t)(wave + ES_WAVES * j) * 1024u);
     };
     dma(0);
     dma(1);
@@ -264,17 +267,17 @@ template <int D>
 static void launch_stream(wsae_ctx* c, const bf16_t* x, const int32_t* rows, int B, int NQ, int SP, float* pre, float* smax,
                           int64_t* step_count, hipStream_t st) {
     const int lds = ES_RING * 32 * D * 2 + SP * 32 * 4;
-    encode_stream_kernel<D><<<(B / ES_ROWS) * NQ, 256, lds, st>>>(x, rows, c->We_bf16, c->c_fold, B, c->H, NQ, SP, pre, smax,
+    encode_stream_kernel<D><<<(B / ES_ROWS) * NQ, 64 * ES_WAVES, lds, st>>>(x, rows, c->We_bf16, c->c_fold, B, c->H, NQ, SP, pre, smax,
                                                                  step_count);
 }
 
 }  // namespace
 
-// parts per row tile for this batch: enough workgroups for two per CU, at least 4 slabs per part
+// parts per row tile for this batch: enough workgroups for one per CU, at least 4 slabs per part
 static int es_parts(const wsae_ctx* c, int B) {
     const int slabs = c->H / 32, tiles = B / ES_ROWS;
     int nq = 1;
-    while (nq < 16 && tiles * nq < 2 * c->cus && slabs % (2 * nq) == 0 && slabs / (2 * nq) >= 4) nq *= 2;
+    while (nq < 16 && tiles * nq < c->cus && slabs % (2 * nq) == 0 && slabs / (2 * nq) >= 4) nq *= 2;
     return nq;
 }
 
