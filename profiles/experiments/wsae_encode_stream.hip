@@ -172,18 +172,53 @@ encode_stream_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ r
     const char* pre_part = (const char*)pre + (int64_t)part * SP * 32 * 4;
     const char* smax_part = (const char*)smax + (int64_t)part * SP * 2 * 4;
 
-    // write register r of a finished slab: the value as it stands (two 128-byte row segments per store), then its
-    // 16-lane strip maximum (row_shr 1, 2, 4, 8 leave it in the strip's last lane), stored by lanes 15, 31, 47, 63
-    const unsigned long long strip_last = 0x8000800080008000ull;  // lanes 15, 31, 47, 63
-    auto emit_one = [&](int r, float v, const char* pbase, const char* sbase) {
-        asm volatile("global_store_dword %0, %1, %2" ::"v"(o_pre[r]), "v"(v), "s"(pbase) : "memory");
-        float mx = v;
-        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(mx), __float_as_int(mx), 0x111, 0xF, 0xF, false)));
-        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(mx), __float_as_int(mx), 0x112, 0xF, 0xF, false)));
-        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(mx), __float_as_int(mx), 0x114, 0xF, 0xF, false)));
-        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(mx), __float_as_int(mx), 0x118, 0xF, 0xF, false)));
-        asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dword %0, %1, %2\n\ts_mov_b64 exec, -1"
-                     ::"v"(o_smax[r]), "v"(mx), "s"(sbase), "s"(strip_last) : "memory");
+    // Emit a finished slab in groups of four registers (one group per MFMA gap):
+    //   * the values as they stand: register r of a half-wave is 32 consecutive floats of one row, two 128-byte segments
+    //     per store;
+    //   * their 16-lane strip maxima: v_max_f32 with a DPP row shift of 1, 2, 4, 8 leaves the maximum in the strip's last
+    //     lane (lanes without a source keep their value); the four registers' chains are interleaved, so a shifted
+    //     read never follows the write of its source by less than three instructions;
+    //   * the maxima go to a 64-float LDS row of the wave (lanes 15, 31, 47, 63 of register r -> slots 4 r + 0..3) and
+    //     leave as ONE store per slab: a store instruction costs the memory pipe the same with 4 lanes as with 64.
+    const uint32_t smax_row_lds = smem_lds + ES_RING * SLAB + 8 * 1024 + (uint32_t)wave * 256u;
+    // lane l of the slab's one strip-maximum store: register l >> 2, source lane 15 + 16 (l & 3) = half (l & 3) >> 1, strip l & 1
+    const uint32_t o_smax_lane = ((uint32_t)(row0 + es_row_of(lane >> 2) + 4 * ((lane & 3) >> 1)) * (uint32_t)(H >> 4) + (uint32_t)(lane & 1)) * 4u;
+    const uint32_t my_slot = smax_row_lds + (uint32_t)(lane >> 4) * 4u;  // (for lanes 15, 31, 47, 63: + 16 r added per register)
+    const unsigned long long strip_last = 0x8000800080008000ull;          // lanes 15, 31, 47, 63
+    auto emit_four = [&](int r0, const f32x16& v, const char* pbase) {
+        float m0 = v[r0], m1 = v[r0 + 1], m2 = v[r0 + 2], m3 = v[r0 + 3];
+        asm volatile("global_store_dword %4, %0, %8\n\t"
+                     "global_store_dword %5, %1, %8\n\t"
+                     "global_store_dword %6, %2, %8\n\t"
+                     "global_store_dword %7, %3, %8"
+                     :: "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(o_pre[r0]), "v"(o_pre[r0 + 1]), "v"(o_pre[r0 + 2]), "v"(o_pre[r0 + 3]), "s"(pbase)
+                     : "memory");
+#define ES_DPP(sh)                                                                   \
+        asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:" #sh " row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_max_f32_dpp %1, %1, %1 row_shr:" #sh " row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_max_f32_dpp %2, %2, %2 row_shr:" #sh " row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_max_f32_dpp %3, %3, %3 row_shr:" #sh " row_mask:0xf bank_mask:0xf"      \
+                     : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3))
+        ES_DPP(1);
+        ES_DPP(2);
+        ES_DPP(4);
+        ES_DPP(8);
+#undef ES_DPP
+        asm volatile("s_mov_b64 exec, %5\n\t"
+                     "ds_write_b32 %4, %0 offset:%6\n\t"
+                     "ds_write_b32 %4, %1 offset:%7\n\t"
+                     "ds_write_b32 %4, %2 offset:%8\n\t"
+                     "ds_write_b32 %4, %3 offset:%9\n\t"
+                     "s_mov_b64 exec, -1"
+                     :: "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(my_slot), "s"(strip_last), "n"(16 * r0), "n"(16 * r0 + 16),
+                        "n"(16 * r0 + 32), "n"(16 * r0 + 48)
+                     : "memory");
+    };
+    // after the 16th register: the wave's 64 maxima as one store
+    auto emit_smax = [&](const char* sbase) {
+        float mv;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(mv) : "v"(smax_row_lds + (uint32_t)lane * 4u) : "memory");
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(o_smax_lane), "v"(mv), "s"(sbase) : "memory");
     };
 
     // one slab: KS MFMAs with their B fragments (feature row m of the slab) ES_AHEAD K steps ahead - an LDS read takes
@@ -208,12 +243,8 @@ encode_stream_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ r
             lds_wait_for(w[ks % R], (KS - 1 - ks) < ES_AHEAD ? (KS - 1 - ks) : ES_AHEAD);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks], w[ks % R], acc, 0, 0, 0);
             if constexpr (EMIT) {
-                if (KS >= 16) {
-                    if (ks < 16) emit_one(ks, prev[ks], pbase, sbase);
-                } else {  // fewer MFMAs than registers: two per gap
-                    if (2 * ks < 16) emit_one(2 * ks, prev[2 * ks], pbase, sbase);
-                    if (2 * ks + 1 < 16) emit_one(2 * ks + 1, prev[2 * ks + 1], pbase, sbase);
-                }
+                if (ks < 4) emit_four(4 * ks, prev, pbase);
+                else if (ks == 4) emit_smax(sbase);
             }
         }
         const float b = bias_s[s * 32 + m];
@@ -234,13 +265,13 @@ encode_stream_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ r
         }
     };
     // Retire slab s's DMA and meet the other waves.  s_waitcnt vmcnt(N) with N = the operations issued AFTER slab s's
-    // pieces leaves exactly those in flight: the next slab's PW pieces and the 32 stores emitted in the MFMA gaps since
+    // pieces leaves exactly those in flight: the next slab's PW pieces and the 17 stores emitted in the MFMA gaps since
     // (every one of them is issued: none sits under an empty mask).  Counting fewer than were issued only waits longer.
     auto slab_begin = [&](int s) {
         const bool more = s + 1 < SP;
         if (s < 2) { if (more) vm_wait<PW>(); else vm_wait<0>(); }
-        else if (more) vm_wait<PW + 32>();
-        else vm_wait<32>();
+        else if (more) vm_wait<PW + 17>();
+        else vm_wait<17>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
@@ -249,24 +280,33 @@ encode_stream_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ r
     slab_begin(0);
     if (2 < SP) dma(2);
     slab_any(std::false_type{}, 0, prev, prev);
-    for (int s = 1; s < SP; ++s) {
+    int s = 1;
+    for (; s + 1 < SP; s += 2) {  // (two slabs per trip: the accumulators swap roles instead of being copied)
         slab_begin(s);
         if (s + 2 < SP) dma(s + 2);
         slab_any(std::true_type{}, s, cur, prev);
-        prev = cur;
+        slab_begin(s + 1);
+        if (s + 3 < SP) dma(s + 3);
+        slab_any(std::true_type{}, s + 1, prev, cur);
     }
-    {
-        const char* pbase = pre_part + (int64_t)(SP - 1) * 32 * 4;
-        const char* sbase = smax_part + (int64_t)(SP - 1) * 2 * 4;
+    const char* pbase = pre_part + (int64_t)(SP - 1) * 32 * 4;
+    const char* sbase = smax_part + (int64_t)(SP - 1) * 2 * 4;
+    if (s < SP) {
+        slab_begin(s);
+        slab_any(std::true_type{}, s, cur, prev);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) emit_one(r, prev[r], pbase, sbase);
+        for (int r0 = 0; r0 < 16; r0 += 4) emit_four(r0, cur, pbase);
+    } else {
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 4) emit_four(r0, prev, pbase);
     }
+    emit_smax(sbase);
 }
 
 template <int D>
 static void launch_stream(wsae_ctx* c, const bf16_t* x, const int32_t* rows, int B, int NQ, int SP, float* pre, float* smax,
                           int64_t* step_count, hipStream_t st) {
-    const int lds = ES_RING * 32 * D * 2 + SP * 32 * 4;
+    const int lds = ES_RING * 32 * D * 2 + 8 * 1024 + ES_WAVES * 256;  // ring | bias (<= 8 KB) | one 64-float row per wave
     encode_stream_kernel<D><<<(B / ES_ROWS) * NQ, 64 * ES_WAVES, lds, st>>>(x, rows, c->We_bf16, c->c_fold, B, c->H, NQ, SP, pre, smax,
                                                                  step_count);
 }

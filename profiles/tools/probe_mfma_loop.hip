@@ -25,8 +25,19 @@ __device__ __forceinline__ void lds_wait_for(bf16x8& w, int newer) {
     }
 }
 
+__device__ __forceinline__ void glds16s(const void* base, uint32_t voff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// MODE 4: + the LDS-DMA ring (6 pieces per wave and slab from an L2-resident 2.4 MB matrix, counted vmcnt)
+// MODE 5: as 4 but the DMA'd bytes come from ONE 24 KB slab (every workgroup re-reads the same lines)
+// MODE 6: as 4 without the MFMAs / reads (DMA + barrier only)
 template <int MODE>
-__global__ void __launch_bounds__(256, 2) loop_kernel(float* out, int slabs) {
+__global__ void __launch_bounds__(256, 2) loop_kernel(float* out, int slabs, const char* W = nullptr) {
     constexpr int KS = 24, CPR = 48, SLAB = 32 * 384 * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
@@ -42,9 +53,31 @@ __global__ void __launch_bounds__(256, 2) loop_kernel(float* out, int slabs) {
     f32x16 tot;
 #pragma unroll
     for (int r = 0; r < 16; ++r) tot[r] = 0.f;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t dma_off[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int p = 64 * (wave + 4 * j) + lane;
+        const int r = p / CPR, cpos = p % CPR;
+        dma_off[j] = (uint32_t)(r * 768 + ((cpos & ~15) | ((cpos ^ r) & 15)) * 16);
+    }
+    auto dma = [&](int s) {
+        const char* wb = W + (MODE == 5 ? 0 : (size_t)((s + blockIdx.x * 7) % 96) * SLAB);
+        const uint32_t slot = smem_lds + (uint32_t)(s % 3) * SLAB;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) glds16s(wb, dma_off[j], slot + (uint32_t)(wave + 4 * j) * 1024u);
+    };
+    if (MODE >= 4) { dma(0); dma(1); }
     for (int s = 0; s < slabs; ++s) {
         if (MODE == 3) __builtin_amdgcn_s_barrier();
-        const int SO = 0;
+        if (MODE >= 4) {
+            vm_wait<6>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            dma(s + 2);
+            if (MODE == 6) continue;
+        }
+        const int SO = 0;  // (all modes read slot 0: what is read does not matter, only when)
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -82,16 +115,17 @@ __global__ void __launch_bounds__(256, 2) loop_kernel(float* out, int slabs) {
 template <int MODE>
 void run(const char* name) {
     float* out; hipMalloc(&out, 4096);
+    char* W; hipMalloc(&W, 97 * 32 * 384 * 2); hipMemset(W, 0x3c, 97 * 32 * 384 * 2);
     const int slabs = 2000, blocks = 512;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    loop_kernel<MODE><<<blocks, 256, 3 * 32 * 384 * 2>>>(out, 10);
+    loop_kernel<MODE><<<blocks, 256, 3 * 32 * 384 * 2>>>(out, 10, W);
     hipEventRecord(a);
-    loop_kernel<MODE><<<blocks, 256, 3 * 32 * 384 * 2>>>(out, slabs);
+    loop_kernel<MODE><<<blocks, 256, 3 * 32 * 384 * 2>>>(out, slabs, W);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     // per SIMD: 2 waves x slabs x 24 MFMAs
     printf("%-44s %.3f ms: %.1f ns per slab pair (ideal 640 at 2.4 GHz), %.0f TFLOP/s\n", name, ms, ms * 1e6 / slabs,
-           2.0 * blocks * 4 * slabs * 24 * 32768.0 / (ms * 1e-3) / 1e12);
+           1.0 * blocks * 4 * slabs * 24 * 32768.0 / (ms * 1e-3) / 1e12);
 }
 
 int main() {
@@ -99,5 +133,8 @@ int main() {
     run<1>("asm reads 6 ahead + counted waits");
     run<2>("plain LDS reads");
     run<3>("asm reads + barrier per slab");
+    run<4>("... + LDS-DMA ring (2.4 MB matrix)");
+    run<5>("... + LDS-DMA ring (one 24 KB slab)");
+    run<6>("LDS-DMA ring + barrier only");
     return 0;
 }
