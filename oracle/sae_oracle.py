@@ -534,3 +534,56 @@ def transcoder_backward(W_e, b_e, W_d, b_d, x, target, fwd: dict, mode: str = "f
         dx = dx + g64 @ skip_W.astype(F64)
     out["x"] = dx.astype(F32)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# Cross-layer crosscoder, TopK variant  (sae/crosscoder.py:286-379 on top of :38-283)
+# --------------------------------------------------------------------------------------------
+def crosscoder_forward(W_enc, b_enc, W_dec, b_dec, k, layer_acts, mode: str = "fp32", select=None) -> dict:
+    """crosscoder.py:323-379.  ``W_enc [L, d, S]``, ``W_dec [S, L, d]``, ``b_dec [L, d]``; ``layer_acts`` = list of the
+    L per-layer ``[B, d]`` inputs (internal layer order).  pre = sum_l acts_l @ W_enc[l] + b_enc (:331-338); hidden =
+    scatter(relu(topk(pre))) (:341-343); recon_l = hidden @ W_dec[:, l, :] + b_dec[l] (:181-184); loss = sum_l
+    mean((recon_l - acts_l)^2) (:352-358).  ``"amp"`` rounds the GEMM operands to bf16 as the device's bf16 mode does."""
+    L, d, S = W_enc.shape
+    acts = [np.asarray(a, dtype=F32) for a in layer_acts]
+    rd = bf16_round if mode == "amp" else (lambda a: a)
+    pre64 = np.zeros((acts[0].shape[0], S), dtype=F64)
+    for l in range(L):
+        pre64 += rd(acts[l]).astype(F64) @ rd(W_enc[l]).astype(F64)
+    pre = (pre64 + b_enc.astype(F64)).astype(F32)
+    if select is None:
+        vals, idx = topk_select(pre, k)
+    else:
+        idx = np.asarray(select, dtype=np.int64)
+        vals = np.take_along_axis(pre, idx, axis=1).astype(F32)
+    hidden = densify(vals, idx, S)
+    recon, per_layer = [], []
+    for l in range(L):
+        r = (hidden.astype(F64) @ rd(W_dec[:, l, :]).astype(F64) + b_dec[l].astype(F64)).astype(F32)
+        recon.append(r)
+        e = r.astype(F64) - acts[l].astype(F64)
+        per_layer.append(F32(np.mean(e * e)))
+    loss = F32(np.sum(np.asarray(per_layer, dtype=F64)))
+    l0 = F32((hidden > 0).sum(axis=1).astype(F64).mean())
+    return {"pre": pre, "vals": vals, "idx": idx, "hidden": hidden, "recon": recon, "per_layer_loss": per_layer,
+            "loss": loss, "l0": l0}
+
+
+def crosscoder_backward(W_enc, b_enc, W_dec, b_dec, layer_acts, fwd: dict) -> dict:
+    """Autograd of ``crosscoder_forward``'s loss (fp32 mode): g_l = 2 (recon_l - acts_l) / (B d); dW_dec[:, l, :] =
+    hidden^T g_l; db_dec[l] = sum g_l; dpre = (sum_l g_l W_dec[:, l, :]^T) * 1[hidden > 0]; dW_enc[l] = acts_l^T dpre;
+    db_enc = sum dpre."""
+    L, d, S = W_enc.shape
+    acts = [np.asarray(a, dtype=F64) for a in layer_acts]
+    B = acts[0].shape[0]
+    hidden = fwd["hidden"].astype(F64)
+    g = [2.0 * (fwd["recon"][l].astype(F64) - acts[l]) / (B * d) for l in range(L)]
+    dh = np.zeros((B, S), dtype=F64)
+    dW_dec = np.zeros(W_dec.shape, dtype=F64)
+    for l in range(L):
+        dh += g[l] @ W_dec[:, l, :].astype(F64).T
+        dW_dec[:, l, :] = hidden.T @ g[l]
+    dpre = np.where(hidden > 0, dh, 0.0)
+    dW_enc = np.stack([acts[l].T @ dpre for l in range(L)])
+    return {"W_enc": dW_enc.astype(F32), "b_enc": dpre.sum(axis=0).astype(F32), "W_dec": dW_dec.astype(F32),
+            "b_dec": np.stack([g[l].sum(axis=0) for l in range(L)]).astype(F32)}

@@ -21,6 +21,7 @@ Golden sets (SURVEY.md row C list):
   G12 transcoders: TopKTranscoder / SkipTranscoder forward, gradients, resample (N3)
   G13 per-feature top activations: the reference's TopKTracker over three updates (N4)
   G14 activation producer: extract_features_batch on a seeded random-init tiny Whisper (N2)
+  G15 TopKCrossLayerCrosscoder: seeded init, forward, every gradient, clock, decoder helpers (N4 sibling)
 
 ``python tests/golden/make_golden.py g10 g11`` regenerates only the named sets.
 """
@@ -31,6 +32,8 @@ import json
 import sys
 import tempfile
 from pathlib import Path
+
+sys.dont_write_bytecode = True  # the reference tree is read-only input: importing it must not leave __pycache__ there
 
 import numpy as np
 import torch
@@ -457,7 +460,48 @@ def g14_hooks():
     np.savez_compressed(HERE / "g14_hooks.npz", **out)
 
 
-SETS = {"g14": g14_hooks, "g13": g13_feature_topk, "g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
+def g15_crosscoder():
+    """TopKCrossLayerCrosscoder (sae/crosscoder.py:286-379): the seeded initialisation, one training-mode forward with
+    every gradient, the dead-feature clock, and the decoder-norm helpers."""
+    from whisper_sae.sae.crosscoder import TopKCrossLayerCrosscoder  # reference
+    d, L, S, K, B = 32, 3, 256, 8, 40
+    layers = [0, 2, 3]
+    torch.manual_seed(42)
+    m = TopKCrossLayerCrosscoder(d_model=d, n_layers=L, d_sae=S, k=K, layer_indices=layers, dead_feature_threshold=20)
+    out = {"dims": np.array([d, L, S, K, B]), "layers": np.array(layers),
+           "init.W_dec": m.W_dec.detach().numpy().copy(), "init.W_enc_digest": tensor_digest(m.W_enc.detach().numpy())}
+    with torch.no_grad():  # non-trivial biases so their gradients / use are exercised
+        m.b_enc.copy_(torch.from_numpy(synth.uniform((S,), 29, 1, -0.05, 0.05)))
+        m.b_dec.copy_(torch.from_numpy(synth.uniform((L, d), 29, 2, -0.05, 0.05)))
+        m.W_enc.add_(torch.from_numpy((synth.normal((L, d, S), 29, 3) * np.float32(0.02)).astype(np.float32)))
+    acts = {li: synth.activations(B, d, seed=29, stream=10 + i, bf16=False) for i, li in enumerate(layers)}
+    m.train()
+    o = m({li: torch.from_numpy(a) for li, a in acts.items()})
+    o.loss.backward()
+    out.update({"W_enc": m.W_enc.detach().numpy().copy(), "b_enc": m.b_enc.detach().numpy().copy(),
+                "b_dec": m.b_dec.detach().numpy().copy(),
+                "acts": np.stack([acts[li] for li in layers]),
+                "recon": np.stack([o.reconstructed[li].detach().numpy() for li in layers]),
+                "per_layer_loss": np.array([o.per_layer_loss[li].item() for li in layers], dtype=np.float32),
+                "loss": np.float32(o.loss.item()), "l0": np.float32(o.l0.item()),
+                "idx": np.sort(np.argsort(-o.hidden.detach().numpy(), axis=1, kind="stable")[:, :K], axis=1).astype(np.int16),
+                "nnz": (o.hidden.detach().numpy() > 0).sum(axis=1).astype(np.int16),
+                "dW_enc": m.W_enc.grad.numpy(), "db_enc": m.b_enc.grad.numpy(), "dW_dec": m.W_dec.grad.numpy(),
+                "db_dec": m.b_dec.grad.numpy(), "step_count": np.int64(m.step_count.item()),
+                "last_activated": m.feature_last_activated.numpy().copy(),
+                "decoder_norms": m.get_decoder_norms().detach().numpy(),
+                "layer_norms": m.get_feature_layer_norms().detach().numpy(),
+                "cross_layer": m.get_cross_layer_features(0.5).numpy()})
+    # encode from a subset of the layers (the others contribute nothing, crosscoder.py:331-336)
+    sub = m.encode({2: torch.from_numpy(acts[2])}).detach().numpy()
+    out["subset.nnz_idx"] = np.sort(np.argsort(-sub, axis=1, kind="stable")[:, :K], axis=1).astype(np.int16)
+    out["subset.hidden_sum"] = sub.sum(axis=1)
+    m.normalize_decoder_weights()
+    out["normalized.W_dec"] = m.W_dec.detach().numpy().copy()
+    np.savez_compressed(HERE / "g15_crosscoder.npz", **out)
+
+
+SETS = {"g15": g15_crosscoder, "g14": g14_hooks, "g13": g13_feature_topk, "g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
         "g10": g10_seeded_init, "g11": g11_cache_interchange}
 
 if __name__ == "__main__":

@@ -80,7 +80,7 @@ class _SparsePath(torch.autograd.Function):
         step_ptr = module.step_count.data_ptr() if training else 0
         last_ptr = module.feature_last_activated.data_ptr() if training else 0
         pk = eng.pack.data_ptr()
-        N.check(lib.wsae_ctx_set_loss_cols(handle, dout), "wsae_ctx_set_loss_cols")
+        N.check(lib.wsae_ctx_set_loss_cols(handle, module._mse_cols()), "wsae_ctx_set_loss_cols")
         N.check(lib.wsae_ctx_set_fired(handle, 0), "wsae_ctx_set_fired")
         N.check(lib.wsae_encode_topk(handle, pk, x2.data_ptr(), _dtype_code(x2), 0, B, vals.data_ptr(), idx.data_ptr(),
                                      step_ptr, eng.stats.data_ptr(), st), "wsae_encode_topk")
@@ -118,7 +118,7 @@ class _SparsePath(torch.autograd.Function):
         handle = eng.prepare(prec, B, force=True)
         pk = eng.pack.data_ptr()
         need = ctx.needs_input_grad
-        N.check(lib.wsae_ctx_set_loss_cols(handle, dout), "wsae_ctx_set_loss_cols")
+        N.check(lib.wsae_ctx_set_loss_cols(handle, module._mse_cols()), "wsae_ctx_set_loss_cols")
         if eng.generation != ctx.gen or not ctx.has_dpre:
             # another call has reused the ctx workspace since: restage this batch (input, then g / dpre from the target)
             tmp_v, tmp_i = torch.empty_like(vals), torch.empty_like(idx)
@@ -183,9 +183,14 @@ class _TranscoderBase(nn.Module):
             return v[:self.output_dim]
         return v
 
+    def _mse_cols(self) -> int:
+        """Columns the reconstruction MSE averages over (``wsae_ctx_set_loss_cols``)."""
+        return self.output_dim
+
     def bind(self) -> SAEEngine:
-        dev = self.encoder.weight.device
-        require_device_tensor(self.encoder.weight, type(self).__name__)
+        anchor = self._named_core_params()["encoder.weight"]
+        dev = anchor.device
+        require_device_tensor(anchor, type(self).__name__)
         if self.k > self.hidden_dim:
             raise ValueError(f"k={self.k} exceeds hidden_dim={self.hidden_dim}")
         eng = self._engine
@@ -313,7 +318,7 @@ class TopKTranscoder(_TranscoderBase):
         if int(eng.stats[5].item()) == 0:
             return 0
         training = self.training
-        N.check(lib.wsae_ctx_set_loss_cols(handle, self.output_dim), "wsae_ctx_set_loss_cols")
+        N.check(lib.wsae_ctx_set_loss_cols(handle, self._mse_cols()), "wsae_ctx_set_loss_cols")
         N.check(lib.wsae_ctx_set_fired(handle, 0), "wsae_ctx_set_fired")
         vals = torch.empty(Br, eng.k, dtype=torch.float32, device=eng.device)
         idx = torch.empty(Br, eng.k, dtype=torch.int32, device=eng.device)
