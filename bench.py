@@ -104,11 +104,19 @@ def main() -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    # WSAE_BENCH_REHEARSE=1: walk the N > 1 code on a ONE-GPU box - every rank on cuda:0, gloo instead of RCCL.  The line
+    # it prints carries "rehearsal": true and is not a measurement.
+    rehearse = world > 1 and os.environ.get("WSAE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     B = args.batch
     torch.manual_seed(42)  # same initial weights on every rank (scripts/train.py:84-90 seeds before create_sae)
@@ -212,6 +220,7 @@ def main() -> None:
                        "batch_per_gpu": B, "global_batch": world * B, "ring_rows_per_gpu": args.ring_rows,
                        "lr": 1e-4, "clip": 1.0, "parallelism": f"dp{world}",
                        **({"grad_exchange": trainer.grad_exchange} if world > 1 else {})},
+            **({"rehearsal": True} if rehearse else {}),
             "roofline": roof,
             "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS,
             "final_loss": last.loss if last is not None else None,
