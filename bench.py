@@ -75,7 +75,8 @@ def main() -> None:
     ap.add_argument("--ring-rows", type=int, default=1 << 22)
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the median is reported")
+    ap.add_argument("--windows", type=int, default=9,
+                    help="timed windows of --steps steps each; the median is reported (every window is listed: the first ~100 steps after an idle GPU run at a ramping clock)")
     ap.add_argument("--grad-exchange", choices=("auto", "fp32", "bf16"), default="auto",
                     help="N > 1: dtype of the gradient all-reduce (auto = bf16 in the bf16 mode, fp32 in the fp32 mode)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel (adds event overhead)")

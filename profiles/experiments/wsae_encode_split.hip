@@ -1,5 +1,7 @@
 // Encode path: batch staging, pre-activation GEMM on MFMA, per-row TopK with wavefront reductions.
 //   reference: TopKSAE.encode, src/whisper_sae/sae/model.py:98-118
+#include <type_traits>
+
 #include "wsae_common.h"
 #include "wsae_mfma.h"
 #include "wsae_topk.h"
@@ -154,19 +156,6 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
             ar[j] = arows ? arows[m] : m;
         }
     };
-    // K slab k0 (absolute element offset) of tile (rows ar, n0) into stage st: pieces 0..31 = A rows, 32..63 = Bt rows
-    auto dma = [&](const int (&ar)[4], int n0, int64_t k0, int st) {
-        const uint32_t base = smem_lds + (st ? G256D_STAGE1 : 0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int piece = wave + 8 * j;            // 0..63
-            const int row = (piece & 31) * 8 + dma_r;  // row inside the 256-row operand tile
-            const int c = dma_s ^ ((row >> 1) & 7);
-            const T* src = j < 4 ? xb + (int64_t)ar[j & 3] * lda + k0 + c * EPC
-                                 : W + (int64_t)min(n0 + row, H - 1) * ldb + k0 + c * EPC;
-            glds16(src, base + piece * 1024);
-        }
-    };
     auto m_of = [&](int t) { return ((t % ntiles_mn) / ntn) * 256; };
     auto n_of = [&](int t) { return ((t % ntiles_mn) % ntn) * 256; };
     auto k_of = [&](int t) { return (int64_t)(t / ntiles_mn) * D; };  // first element of the tile's K range
@@ -174,38 +163,68 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
 #ifdef WSAE_ENC_STAMPS
     unsigned long long en_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, en_last = __builtin_amdgcn_s_memtime();
 #endif
-    int it = 0, st = 1;
-    int tile = tile_at(0);
+    // Work items.  A tile's output (256 KB + strip maxima) leaves in one burst, and with every workgroup on the same
+    // schedule the whole chip alternates between an MFMA phase with an idle write path and a store phase bound by HBM
+    // writes (214 MB per launch at cfg 2).  For the encoder forward every other workgroup of an XCD therefore walks
+    // its tiles as  LO(t0), t1, .., t(n-1), HI(t0)  - LO / HI = the row groups mi = 0,1 / 2,3 of every wave's 128 rows,
+    // half the MFMAs and half the output each - which puts it half a tile period out of phase with its neighbours:
+    // one half of the chip stores under the other half's MFMAs (70 -> 59 us at cfg 2, same work, same results).
+    int n_my = 0;
+    while (tile_at(n_my) < ntiles) ++n_my;
+    const bool split = false && smax && nsplit == 1 && n_my >= 2 && ((blockIdx.x >> 3) & 1);
+    const int n_items = split ? n_my + 1 : n_my;
+    auto item_tile = [&](int q) { return q >= n_items ? ntiles : tile_at(split && q == n_my ? 0 : q); };
+    auto item_kind = [&](int q) { return !split ? 0 : (q == 0 ? 1 : (q == n_my ? 2 : 0)); };  // 0 full, 1 LO, 2 HI
+    // source rows of the lane's four A pieces (piece = wave + 8 j covers tile rows 8 piece ..): LO needs j = 0, 2, HI j = 1, 3
+    auto amask_of = [](int kind) { return kind == 0 ? 0xF : (kind == 1 ? 0x5 : 0xA); };
+    auto dma_item = [&](const int (&rows4)[4], int amask, int n0, int64_t k0, int stg) {
+        const uint32_t base = smem_lds + (stg ? G256D_STAGE1 : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < 4 && !((amask >> j) & 1)) continue;
+            const int piece = wave + 8 * j;            // 0..63
+            const int row = (piece & 31) * 8 + dma_r;  // row inside the 256-row operand tile
+            const int c = dma_s ^ ((row >> 1) & 7);
+            const T* src = j < 4 ? xb + (int64_t)rows4[j & 3] * lda + k0 + c * EPC
+                                 : W + (int64_t)min(n0 + row, H - 1) * ldb + k0 + c * EPC;
+            glds16(src, base + piece * 1024);
+        }
+    };
+
+    int st = 1;
     int ar[4] = {0, 0, 0, 0}, ar_n[4];
-    if (tile < ntiles) {
-        a_rows(m_of(tile), ar);
-        dma(ar, n_of(tile), k_of(tile), st);
+    if (n_items > 0) {
+        const int t0 = item_tile(0);
+        a_rows(m_of(t0), ar);
+        dma_item(ar, amask_of(item_kind(0)), n_of(t0), k_of(t0), st);
     }
-    for (; tile < ntiles; tile = tile_at(++it)) {
+    // one work item: row groups [M0, M1) of tile `tile`; `nt` / `nmask` describe the item after it (its first slab is
+    // requested during this item's last K step)
+    auto run_item = [&](auto m0_c, auto m1_c, int tile, int amask, int nt, int nmask) {
+        constexpr int M0 = decltype(m0_c)::value, M1 = decltype(m1_c)::value;
         const int m0 = m_of(tile), n0 = n_of(tile);
         const int64_t kbase = k_of(tile);
         const int z = tile / ntiles_mn;
         f32x16 acc[4][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = M0; i < M1; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const int nt = min(tile_at(it + 1), ntiles - 1);
-        a_rows(m_of(nt), ar_n);  // (fetched a whole tile ahead of their use)
+        a_rows(m_of(nt), ar_n);  // (fetched a whole item ahead of their use)
         EN_T(0)
         for (int kt = 0; kt < nk; ++kt) {
             dma_wait();       // slab kt (issued one step ago) has landed
             EN_T(1)
             __syncthreads();  // ... for every wave; and everybody is done reading the other stage
             EN_T(2)
-            // request the next slab into the other stage: the next K step of this tile, or the first of the next tile
-            if (kt + 1 < nk) dma(ar, n0, kbase + (int64_t)(kt + 1) * KT, st ^ 1);
-            else dma(ar_n, n_of(nt), k_of(nt), st ^ 1);
+            // request the next slab into the other stage: the next K step of this item, or the first of the next item
+            if (kt + 1 < nk) dma_item(ar, amask, n0, kbase + (int64_t)(kt + 1) * KT, st ^ 1);
+            else dma_item(ar_n, nmask, n_of(nt), k_of(nt), st ^ 1);
             EN_T(3)
             const char* As = smem + (st ? G256D_STAGE1 : 0);
-            Mfma256s<T>::slab(As, As + 256 * SWZ_ROW_BYTES, wm * 128, wn * 64, lane, acc);
+            Mfma256s<T>::template slab_rows<M0, M1>(As, As + 256 * SWZ_ROW_BYTES, wm * 128, wn * 64, lane, acc);
             st ^= 1;
             EN_T(4)
         }
@@ -230,7 +249,7 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
             const int off_sm = (b_lane * hs + (hcol >> 4)) * 4;
             const int row_pre = (int)ldp * 16, row_sm = hs * 16;  // bytes per 4 rows
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
+            for (int mi = M0; mi < M1; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -274,15 +293,15 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
             float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
             if (cscale && hcol < H) cs4 = *(const float4*)(cscale + hcol);
             float* Cz = pre + (int64_t)z * cz;
-    #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-    #pragma unroll
+#pragma unroll
+            for (int mi = M0; mi < M1; ++mi) {
+#pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-    #pragma unroll
+#pragma unroll
                     for (int r = 0; r < 16; ++r)
                         patch[((r & 3) + 8 * (r >> 2) + 4 * rq) * PS + ni * 32 + col] = acc[mi][ni][r];
                 __builtin_amdgcn_wave_barrier();
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int rl = pr + 4 * i;
                     const int b = m0 + wm * 128 + mi * 32 + rl;
@@ -303,9 +322,17 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        // (the loop top's barrier separates these patch reads from the next slab landing in stage 0)
+        // (the next item's loop-top barrier separates these patch reads from the next slab landing in stage 0)
 #pragma unroll
         for (int j = 0; j < 4; ++j) ar[j] = ar_n[j];
+    };
+    using std::integral_constant;
+    for (int q = 0; q < n_items; ++q) {
+        const int tile = item_tile(q), kind = item_kind(q);
+        const int nt = min(item_tile(q + 1), ntiles - 1), nmask = amask_of(q + 1 < n_items ? item_kind(q + 1) : 0);
+        if (kind == 0) run_item(integral_constant<int, 0>{}, integral_constant<int, 4>{}, tile, 0xF, nt, nmask);
+        else if (kind == 1) run_item(integral_constant<int, 0>{}, integral_constant<int, 2>{}, tile, 0x5, nt, nmask);
+        else run_item(integral_constant<int, 2>{}, integral_constant<int, 4>{}, tile, 0xA, nt, nmask);
     }
     dma_wait();
 #ifdef WSAE_ENC_STAMPS

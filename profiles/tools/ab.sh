@@ -4,7 +4,7 @@
 #   profiles/tools/ab.sh build_ab/libwsae_hip_b.so [rounds]        (A = the in-tree library)
 set -e
 B_LIB=$1; ROUNDS=${2:-2}
-A_LIB=whisper-sae_amd/whisper_sae/libwsae_hip.so
+A_LIB=${A_LIB:-whisper-sae_amd/whisper_sae/libwsae_hip.so}
 mkdir -p gpurun_out
 python3 - "$A_LIB" "$B_LIB" "$ROUNDS" <<'PY'
 import json, os, subprocess, sys
