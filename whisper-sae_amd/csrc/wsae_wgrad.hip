@@ -408,18 +408,44 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
 
     float* dst = out + (int64_t)split * slab_stride + (which == 0 ? (int64_t)H * D : 0);
     const int col = lane & 31, rq = lane >> 5;
+    if (f0 + W2_M <= H && d0 + W2_N <= D) {
+        // Interior tiles: the accumulators go through an LDS patch (the stages are free now) and leave as 16-byte stores,
+        // 36 store instructions per wave instead of 144 four-byte ones.  The tail of this kernel is bound by the number
+        // of store instructions, not by their bytes (bf16 slabs - half the bytes, same instructions - did not move it).
+        constexpr int PSW = 100;  // floats per patch row: 96 + 4 (16-byte aligned rows, conflict-free column writes)
+        float* patch = (float*)smem + wave * 32 * PSW;
+        float* drow = dst + (int64_t)(f0 + wm * 32 * W2_MI) * D + d0 + wn * 96;
 #pragma unroll
-    for (int mi = 0; mi < W2_MI; ++mi)
+        for (int mi = 0; mi < W2_MI; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 3; ++ni) {
-            const int d = d0 + wn * 96 + ni * 32 + col;
-            if (d >= D) continue;
+            for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = f0 + wm * 32 * W2_MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-                if (f < H) dst[(int64_t)f * D + d] = acc[mi][ni][r];
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * rq) * PSW + ni * 32 + col] = acc[mi][ni][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int idx = lane + 64 * i;      // float4 number inside the 32 x 96 patch
+                const int row = idx / 24, c4 = idx - row * 24;
+                const float4 v = *(const float4*)(patch + row * PSW + c4 * 4);
+                *(float4*)(drow + (int64_t)(mi * 32 + row) * D + c4 * 4) = v;
             }
+            __builtin_amdgcn_wave_barrier();
         }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < W2_MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) {
+                const int d = d0 + wn * 96 + ni * 32 + col;
+                if (d >= D) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = f0 + wm * 32 * W2_MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                    if (f < H) dst[(int64_t)f * D + d] = acc[mi][ni][r];
+                }
+            }
+    }
     if (do_dbe && (lane & 15) == 0) {  // column 0 of the ones product = the row sums
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
