@@ -274,15 +274,15 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
             float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
             if (cscale && hcol < H) cs4 = *(const float4*)(cscale + hcol);
             float* Cz = pre + (int64_t)z * cz;
-    #pragma unroll
+#pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-    #pragma unroll
+#pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-    #pragma unroll
+#pragma unroll
                     for (int r = 0; r < 16; ++r)
                         patch[((r & 3) + 8 * (r >> 2) + 4 * rq) * PS + ni * 32 + col] = acc[mi][ni][r];
                 __builtin_amdgcn_wave_barrier();
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int rl = pr + 4 * i;
                     const int b = m0 + wm * 128 + mi * 32 + rl;
