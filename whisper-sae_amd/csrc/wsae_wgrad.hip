@@ -259,7 +259,9 @@ wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid
             Mfma<T>::template slab<false>(As, Bs, wm * 64, wn * 64, lane, acc);
     }
 
-    float* dst = out + (int64_t)split * slab_stride + (which == 0 ? (int64_t)H * D : 0);
+    // slab layout [row of the 2H x D matrix][split][D]: the 8 partial rows grad_finish sums are one contiguous 8 D run
+    const int64_t rstr = (int64_t)WSAE_WGRAD_MAX_SPLIT * D;
+    float* dst = out + (which == 0 ? (int64_t)H * rstr : 0) + (int64_t)split * D;
     const int col = lane & 31, rq = lane >> 5;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -270,7 +272,7 @@ wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int f = f0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-                if (f < H) dst[(int64_t)f * D + d] = acc[mi][ni][r];
+                if (f < H) dst[(int64_t)f * rstr + d] = acc[mi][ni][r];
             }
         }
     if (rs_wave && col == 0) {  // column 0 of the ones product = the row sums
@@ -432,7 +434,9 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
         __syncthreads();
     }
 
-    float* dst = out + (int64_t)split * slab_stride + (which == 0 ? (int64_t)H * D : 0);
+    // slab layout [row of the 2H x D matrix][split][D]: the 8 partial rows grad_finish sums are one contiguous 8 D run
+    const int64_t rstr = (int64_t)WSAE_WGRAD_MAX_SPLIT * D;
+    float* dst = out + (which == 0 ? (int64_t)H * rstr : 0) + (int64_t)split * D;
     const int col = lane & 31, rq = lane >> 5;
     if (f0 + W2_M <= H && d0 + W2_N <= D) {
         // Interior tiles: the accumulators go through an LDS patch (the stages are free now) and leave as 16-byte stores,
@@ -440,7 +444,7 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
         // of store instructions, not by their bytes (bf16 slabs - half the bytes, same instructions - did not move it).
         constexpr int PSW = 100;  // floats per patch row: 96 + 4 (16-byte aligned rows, conflict-free column writes)
         float* patch = (float*)smem + wave * 32 * PSW;
-        float* drow = dst + (int64_t)(f0 + wm * 32 * W2_MI) * D + d0 + wn * 96;
+        float* drow = dst + (int64_t)(f0 + wm * 32 * W2_MI) * rstr + d0 + wn * 96;
 #pragma unroll
         for (int mi = 0; mi < W2_MI; ++mi) {
 #pragma unroll
@@ -454,7 +458,7 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
                 const int idx = lane + 64 * i;      // float4 number inside the 32 x 96 patch
                 const int row = idx / 24, c4 = idx - row * 24;
                 const float4 v = *(const float4*)(patch + row * PSW + c4 * 4);
-                *(float4*)(drow + (int64_t)(mi * 32 + row) * D + c4 * 4) = v;
+                *(float4*)(drow + (int64_t)(mi * 32 + row) * rstr + c4 * 4) = v;
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -468,7 +472,7 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int f = f0 + wm * 32 * W2_MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
-                    if (f < H) dst[(int64_t)f * D + d] = acc[mi][ni][r];
+                    if (f < H) dst[(int64_t)f * rstr + d] = acc[mi][ni][r];
                 }
             }
     }
@@ -520,45 +524,71 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
     const int nlat = nblk_h + DBD_L1;
     const int bid = (int)blockIdx.x >= nlat ? (int)blockIdx.x - nlat : nrb + (int)blockIdx.x;
     if (bid < nrb) {
-        // one wave per row of the [2 H][D] gradient matrix (rows < H: dW_e, the rest dW_dT), `rpw` consecutive rows
-        // per wave: all slab loads of a row piece (8 independent 16-byte loads per lane) are in flight together -
-        // a loop over the splits with one load per trip ran at half the HBM rate
+        // A wave owns `rpw` consecutive rows of the [2 H][D] gradient matrix (rows < H: dW_e, the rest dW_dT) and walks them
+        // two at a time as ONE contiguous range of float4 chunks: every slab load of up to TR full trips (8 splits x TR
+        // independent 16-byte loads per lane) is in flight before anything is summed.  (Row by row, a 96-chunk row is one
+        // full trip and one half-empty trip, each a separate round of memory latency: 22 us for 75 MB.)
+        static_assert(WSAE_WGRAD_MAX_SPLIT == 8, "the db_e gather below packs (row, split) into lane = 8 row + split");
+        constexpr int TR = 3;
         const int lane = tid & 63, wave = tid >> 6;
         const int rows_total = 2 * H, nc = D >> 2;  // float4 chunks per row
         const int rpw = (rows_total + nrb * 4 - 1) / (nrb * 4);
         float sq = 0.f;  // sum of squares of everything this block writes (global-norm partial)
-        for (int q = 0; q < rpw; ++q) {
-            const int r = (bid * 4 + wave) * rpw + q;
-            if (r >= rows_total) break;
-            float be = 0.f;
-            if (r < H) {  // db_e[h] = sum over splits, in split order (the db_pre blocks below use the same order)
-                const float v = lane < nsplit ? dbe_slab[(int64_t)lane * H + r] : 0.f;
+        for (int q = 0; q < rpw; q += 2) {
+            const int r0 = (bid * 4 + wave) * rpw + q;
+            if (r0 >= rows_total) break;
+            const int nr = min(2, min(rpw - q, rows_total - r0));
+            // db_e[h] = sum over splits, in split order (the db_pre blocks below use the same order)
+            float be[2] = {0.f, 0.f};
+            {
+                const int j = lane >> 3, sp = lane & 7;
+                const float v = (j < nr && sp < nsplit && r0 + j < H) ? dbe_slab[(int64_t)sp * H + r0 + j] : 0.f;
 #pragma unroll
-                for (int sp = 0; sp < WSAE_WGRAD_MAX_SPLIT; ++sp) be += __shfl(v, sp, 64);
+                for (int s2 = 0; s2 < WSAE_WGRAD_MAX_SPLIT; ++s2) {
+                    be[0] += __shfl(v, s2, 64);
+                    be[1] += __shfl(v, 8 + s2, 64);
+                }
                 if (lane == 0) {
-                    dbe_out[r] = be;
-                    sq = fmaf(be, be, sq);
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; ++j2)
+                        if (j2 < nr && r0 + j2 < H) {
+                            dbe_out[r0 + j2] = be[j2];
+                            sq = fmaf(be[j2], be[j2], sq);
+                        }
                 }
             }
-            const float4* base = (const float4*)slabs + (int64_t)r * nc;
-            for (int c = lane; c < nc; c += 64) {
-                float4 v[WSAE_WGRAD_MAX_SPLIT];
+            const int total = nr * nc;
+            const float4* base = (const float4*)slabs + (int64_t)r0 * WSAE_WGRAD_MAX_SPLIT * nc;  // [row][split][D]
+            for (int c0 = 0; c0 < total; c0 += 64 * TR) {
+                float4 v[TR][WSAE_WGRAD_MAX_SPLIT];
 #pragma unroll
-                for (int sp = 0; sp < WSAE_WGRAD_MAX_SPLIT; ++sp)  // splits past nsplit re-read the last one (weight 0)
-                    v[sp] = base[(int64_t)min(sp, nsplit - 1) * (slab_stride >> 2) + c];
-                float4 a = v[0];
+                for (int t = 0; t < TR; ++t) {
+                    const int idx = min(c0 + lane + 64 * t, total - 1);  // clamped: unconditional loads
+                    const int jr = idx >= nc ? 1 : 0, cc = idx - jr * nc;
 #pragma unroll
-                for (int sp = 1; sp < WSAE_WGRAD_MAX_SPLIT; ++sp) {
-                    const float w = sp < nsplit ? 1.f : 0.f;
-                    a.x = fmaf(w, v[sp].x, a.x); a.y = fmaf(w, v[sp].y, a.y);
-                    a.z = fmaf(w, v[sp].z, a.z); a.w = fmaf(w, v[sp].w, a.w);
+                    for (int sp = 0; sp < WSAE_WGRAD_MAX_SPLIT; ++sp)  // splits past nsplit re-read the last one (weight 0)
+                        v[t][sp] = base[(jr * WSAE_WGRAD_MAX_SPLIT + min(sp, nsplit - 1)) * nc + cc];
                 }
-                if (FOLD && r < H) {
-                    const float4 bp = *(const float4*)(bpre + 4 * c);
-                    a.x -= be * bp.x; a.y -= be * bp.y; a.z -= be * bp.z; a.w -= be * bp.w;
+#pragma unroll
+                for (int t = 0; t < TR; ++t) {
+                    const int idx = c0 + lane + 64 * t;
+                    if (idx >= total) continue;
+                    float4 a = v[t][0];
+#pragma unroll
+                    for (int sp = 1; sp < WSAE_WGRAD_MAX_SPLIT; ++sp) {
+                        const float w = sp < nsplit ? 1.f : 0.f;
+                        a.x = fmaf(w, v[t][sp].x, a.x); a.y = fmaf(w, v[t][sp].y, a.y);
+                        a.z = fmaf(w, v[t][sp].z, a.z); a.w = fmaf(w, v[t][sp].w, a.w);
+                    }
+                    const int j = idx >= nc ? 1 : 0, c = idx - j * nc;
+                    if (FOLD && r0 + j < H) {
+                        const float4 bp = *(const float4*)(bpre + 4 * c);
+                        const float b1 = j ? be[1] : be[0];
+                        a.x -= b1 * bp.x; a.y -= b1 * bp.y; a.z -= b1 * bp.z; a.w -= b1 * bp.w;
+                    }
+                    ((float4*)grads)[(int64_t)r0 * nc + idx] = a;
+                    sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
                 }
-                ((float4*)grads)[(int64_t)r * nc + c] = a;
-                sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
             }
         }
         const float t = block_sum(sq, red);
