@@ -307,6 +307,12 @@ int wsae_feature_topk_update(const float* vals, const int32_t* idx, int64_t rows
  * mode only; hidden, loss and the whole backward stay on the bf16 path.  Needs batch >= 512, input_dim % 256 == 0,
  * hidden_dim % 256 == 0. */
 int wsae_ctx_set_relu_fp8(wsae_ctx* ctx, int32_t on);
+/* Per-feature weights w[hidden_dim] of the L1 term (device memory, caller-owned, must outlive the calls; NULL = all ones, the
+ * default): the sparsity term of wsae_relu_forward becomes sum_b sum_s w[s] |hidden[b][s]| / (B H) and wsae_relu_backward adds
+ * sparsity_weight * w[s] / (B H) to dL/dhidden[b][s] (w itself is a constant of the step).  The cross-layer crosscoder
+ * (crosscoder.py:213-217: decoder-norm-weighted L1, mean over the batch of the row sums) passes the decoder norms and
+ * sparsity_weight * H.  The MSE of the ReLU path divides by B * loss_cols (wsae_ctx_set_loss_cols), as the TopK path does. */
+int wsae_ctx_set_relu_l1_weights(wsae_ctx* ctx, const float* weights);
 int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                       const int32_t* rows, int32_t B, float sparsity_weight, float* hidden,
                       float* recon, wsae_stats* stats, float* sparsity_loss_out, void* stream);

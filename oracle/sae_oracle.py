@@ -587,3 +587,46 @@ def crosscoder_backward(W_enc, b_enc, W_dec, b_dec, layer_acts, fwd: dict) -> di
     dW_enc = np.stack([acts[l].T @ dpre for l in range(L)])
     return {"W_enc": dW_enc.astype(F32), "b_enc": dpre.sum(axis=0).astype(F32), "W_dec": dW_dec.astype(F32),
             "b_dec": np.stack([g[l].sum(axis=0) for l in range(L)]).astype(F32)}
+
+
+def crosscoder_relu_forward(W_enc, b_enc, W_dec, b_dec, layer_acts, sparsity_weight: float) -> dict:
+    """CrossLayerCrosscoder with activation "relu" (crosscoder.py:142-235): hidden = relu(sum_l acts_l @ W_enc[l] + b_enc);
+    loss = sum_l mean((recon_l - acts_l)^2) + sparsity_weight * mean_b(sum_s |h_bs| n_s), n_s = ||W_dec[s].flatten()||."""
+    L, d, S = W_enc.shape
+    acts = [np.asarray(a, dtype=F32) for a in layer_acts]
+    pre = np.zeros((acts[0].shape[0], S), dtype=F64)
+    for l in range(L):
+        pre += acts[l].astype(F64) @ W_enc[l].astype(F64)
+    hidden = np.maximum((pre + b_enc.astype(F64)).astype(F32), F32(0))
+    recon, per_layer = [], []
+    for l in range(L):
+        r = (hidden.astype(F64) @ W_dec[:, l, :].astype(F64) + b_dec[l].astype(F64)).astype(F32)
+        recon.append(r)
+        e = r.astype(F64) - acts[l].astype(F64)
+        per_layer.append(F32(np.mean(e * e)))
+    norms = np.sqrt((W_dec.astype(F64).reshape(S, -1) ** 2).sum(axis=1))
+    sparsity = F32(np.mean(np.abs(hidden).astype(F64) @ norms))
+    recon_loss = F32(np.sum(np.asarray(per_layer, dtype=F64)))
+    return {"hidden": hidden, "recon": recon, "per_layer_loss": per_layer, "reconstruction_loss": recon_loss,
+            "sparsity_loss": sparsity, "loss": F32(F64(recon_loss) + sparsity_weight * F64(sparsity)),
+            "l0": F32((hidden > 0).sum(axis=1).astype(F64).mean()), "norms": norms.astype(F32)}
+
+
+def crosscoder_relu_backward(W_enc, b_enc, W_dec, b_dec, layer_acts, fwd: dict, sparsity_weight: float) -> dict:
+    """Autograd of the above: g_l = 2 r_l / (B d); dpre = (sum_l g_l W_dec[:, l]^T + sparsity_weight n_s / B) 1[h > 0];
+    dW_dec[s, l] = h_s^T g_l + sparsity_weight mean_b|h_bs| W_dec[s, l] / n_s (the norm's own gradient)."""
+    L, d, S = W_enc.shape
+    acts = [np.asarray(a, dtype=F64) for a in layer_acts]
+    B = acts[0].shape[0]
+    hidden = fwd["hidden"].astype(F64)
+    norms = fwd["norms"].astype(F64)
+    g = [2.0 * (fwd["recon"][l].astype(F64) - acts[l]) / (B * d) for l in range(L)]
+    dh = np.zeros((B, S), dtype=F64) + sparsity_weight * norms[None, :] / B
+    dW_dec = np.zeros(W_dec.shape, dtype=F64)
+    for l in range(L):
+        dh += g[l] @ W_dec[:, l, :].astype(F64).T
+        dW_dec[:, l, :] = hidden.T @ g[l]
+    dW_dec += (sparsity_weight * np.abs(hidden).mean(axis=0) / norms)[:, None, None] * W_dec.astype(F64)
+    dpre = np.where(hidden > 0, dh, 0.0)
+    return {"W_enc": np.stack([acts[l].T @ dpre for l in range(L)]).astype(F32), "b_enc": dpre.sum(axis=0).astype(F32),
+            "W_dec": dW_dec.astype(F32), "b_dec": np.stack([g[l].sum(axis=0) for l in range(L)]).astype(F32)}

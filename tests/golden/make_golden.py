@@ -22,6 +22,7 @@ Golden sets (SURVEY.md row C list):
   G13 per-feature top activations: the reference's TopKTracker over three updates (N4)
   G14 activation producer: extract_features_batch on a seeded random-init tiny Whisper (N2)
   G15 TopKCrossLayerCrosscoder: seeded init, forward, every gradient, clock, decoder helpers (N4 sibling)
+  G16 CrossLayerCrosscoder (ReLU + decoder-norm-weighted L1): forward, every gradient, clock
 
 ``python tests/golden/make_golden.py g10 g11`` regenerates only the named sets.
 """
@@ -501,7 +502,39 @@ def g15_crosscoder():
     np.savez_compressed(HERE / "g15_crosscoder.npz", **out)
 
 
-SETS = {"g15": g15_crosscoder, "g14": g14_hooks, "g13": g13_feature_topk, "g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
+def g16_crosscoder_relu():
+    """CrossLayerCrosscoder with activation "relu" (sae/crosscoder.py:38-283): one training-mode forward on non-unit
+    decoder norms (so the norm weights and their own gradient matter), every gradient, the clock."""
+    from whisper_sae.sae.crosscoder import CrossLayerCrosscoder  # reference
+    d, L, S, B, lam = 32, 3, 256, 40, 0.05
+    layers = [1, 2, 5]
+    torch.manual_seed(7)
+    m = CrossLayerCrosscoder(d_model=d, n_layers=L, d_sae=S, layer_indices=layers, sparsity_weight=lam, dead_feature_threshold=20)
+    with torch.no_grad():
+        m.b_enc.copy_(torch.from_numpy(synth.uniform((S,), 31, 1, -0.05, 0.05)))
+        m.b_dec.copy_(torch.from_numpy(synth.uniform((L, d), 31, 2, -0.05, 0.05)))
+        m.W_enc.add_(torch.from_numpy((synth.normal((L, d, S), 31, 3) * np.float32(0.02)).astype(np.float32)))
+        m.W_dec.mul_(torch.from_numpy(synth.uniform((S, 1, 1), 31, 4, 0.5, 2.0)))   # decoder norms 0.05 .. 0.2
+    acts = {li: synth.activations(B, d, seed=31, stream=10 + i, bf16=False) for i, li in enumerate(layers)}
+    m.train()
+    o = m({li: torch.from_numpy(a) for li, a in acts.items()})
+    o.loss.backward()
+    out = {"dims": np.array([d, L, S, B]), "layers": np.array(layers), "lam": np.float64(lam),
+           "W_enc": m.W_enc.detach().numpy().copy(), "b_enc": m.b_enc.detach().numpy().copy(),
+           "W_dec": m.W_dec.detach().numpy().copy(), "b_dec": m.b_dec.detach().numpy().copy(),
+           "acts": np.stack([acts[li] for li in layers]),
+           "recon": np.stack([o.reconstructed[li].detach().numpy() for li in layers]),
+           "hidden_digest": tensor_digest(o.hidden.detach().numpy()), "hidden_rowsum": o.hidden.detach().numpy().sum(axis=1),
+           "per_layer_loss": np.array([o.per_layer_loss[li].item() for li in layers], dtype=np.float32),
+           "loss": np.float32(o.loss.item()), "reconstruction_loss": np.float32(o.reconstruction_loss.item()),
+           "sparsity_loss": np.float32(o.sparsity_loss.item()), "l0": np.float32(o.l0.item()),
+           "dW_enc": m.W_enc.grad.numpy(), "db_enc": m.b_enc.grad.numpy(), "dW_dec": m.W_dec.grad.numpy(),
+           "db_dec": m.b_dec.grad.numpy(), "step_count": np.int64(m.step_count.item()),
+           "last_activated": m.feature_last_activated.numpy().copy()}
+    np.savez_compressed(HERE / "g16_crosscoder_relu.npz", **out)
+
+
+SETS = {"g16": g16_crosscoder_relu, "g15": g15_crosscoder, "g14": g14_hooks, "g13": g13_feature_topk, "g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
         "g10": g10_seeded_init, "g11": g11_cache_interchange}
 
 if __name__ == "__main__":

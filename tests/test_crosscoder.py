@@ -67,6 +67,23 @@ class TestOracleAgainstReference:
         assert rel(b["W_d"].T.reshape(S, L, d) * L, g15["dW_dec"]) < 2e-5
 
 
+class TestOracleReluAgainstReference:
+    def test_forward_and_gradients(self, golden_dir):
+        g = np.load(golden_dir / "g16_crosscoder_relu.npz")
+        lam = float(g["lam"])
+        W = (g["W_enc"], g["b_enc"], g["W_dec"], g["b_dec"])
+        acts = list(g["acts"])
+        f = O.crosscoder_relu_forward(*W, acts, lam)
+        assert rel(np.stack(f["recon"]), g["recon"]) < 1e-5
+        assert rel(f["hidden"].sum(axis=1), g["hidden_rowsum"]) < 1e-5
+        for key in ("loss", "reconstruction_loss", "sparsity_loss"):
+            assert abs(float(f[key]) - float(g[key])) / float(g[key]) < 1e-5, key
+        assert float(f["l0"]) == float(g["l0"])
+        b = O.crosscoder_relu_backward(*W, acts, f, lam)
+        for n in ("W_enc", "b_enc", "W_dec", "b_dec"):
+            assert rel(b[n], g[f"d{n}"]) < 2e-5, n
+
+
 class TestHostSurface:
     def test_seeded_initialisation_equals_the_reference(self, g15):
         from whisper_sae.sae.crosscoder import TopKCrossLayerCrosscoder
@@ -209,6 +226,94 @@ class TestDeviceAgainstReference:
         b = O.crosscoder_backward(*W, a, f)
         for n, p in (("W_enc", m.W_enc), ("b_enc", m.b_enc), ("W_dec", m.W_dec), ("b_dec", m.b_dec)):
             assert rel(p.grad.cpu().numpy(), b[n]) < 3e-2, n
+
+
+@pytest.mark.gpu
+class TestReluDeviceAgainstReference:
+    """``CrossLayerCrosscoder(activation="relu")`` on the ReLU-SAE kernels with the decoder norms as L1 weights."""
+
+    def build(self, g, device, precision="fp32"):
+        from whisper_sae.sae.crosscoder import CrossLayerCrosscoder
+        d, L, S, B = (int(v) for v in g["dims"])
+        layers = [int(v) for v in g["layers"]]
+        m = CrossLayerCrosscoder(d_model=d, n_layers=L, d_sae=S, layer_indices=layers, sparsity_weight=float(g["lam"]),
+                                 dead_feature_threshold=20, precision=precision)
+        sd = m.state_dict()
+        for key in ("W_enc", "b_enc", "W_dec", "b_dec"):
+            sd[key] = torch.from_numpy(np.array(g[key]))
+        m.load_state_dict(sd)
+        acts = {li: torch.from_numpy(np.array(g["acts"][i])).to(device) for i, li in enumerate(layers)}
+        return m.to(device), acts, layers, (d, L, S, B)
+
+    def test_forward_gradients_clock_fp32(self, golden_dir, device):
+        g = np.load(golden_dir / "g16_crosscoder_relu.npz")
+        m, acts, layers, (d, L, S, B) = self.build(g, device)
+        m.train()
+        o = m(acts)
+        o.loss.backward()
+        assert rel(torch.stack([o.reconstructed[li] for li in layers]).cpu().numpy(), g["recon"]) < 1e-5
+        assert rel(o.hidden.sum(dim=1).cpu().numpy(), g["hidden_rowsum"]) < 1e-5
+        for key, val in (("loss", o.loss), ("reconstruction_loss", o.reconstruction_loss), ("sparsity_loss", o.sparsity_loss)):
+            assert abs(float(val.detach()) - float(g[key])) / float(g[key]) < 1e-5, key
+        assert rel([float(o.per_layer_loss[li]) for li in layers], g["per_layer_loss"]) < 1e-5
+        assert float(o.l0) == float(g["l0"])
+        for n, p in (("W_enc", m.W_enc), ("b_enc", m.b_enc), ("W_dec", m.W_dec), ("b_dec", m.b_dec)):
+            assert p.grad.shape == g[f"d{n}"].shape
+            assert rel(p.grad.cpu().numpy(), g[f"d{n}"]) < 2e-5, n
+        assert int(m.step_count.item()) == int(g["step_count"])
+        assert np.array_equal(m.feature_last_activated.cpu().numpy(), g["last_activated"])
+        # the module leaves the ctx as the ReLU SAE expects it: a second forward is the same forward
+        o2 = m(acts)
+        assert float(o2.loss.detach()) == float(o.loss.detach())
+
+    def test_sparsity_loss_uses_decoder_norms(self, device):   # reference test of the same name
+        from whisper_sae.sae.crosscoder import CrossLayerCrosscoder
+        torch.manual_seed(1)
+        m = CrossLayerCrosscoder(d_model=64, n_layers=4, d_sae=256, sparsity_weight=0.1, precision="fp32").to(device)
+        acts = {i: torch.randn(8, 64, device=device) for i in range(4)}
+        out = m(acts)
+        expected = torch.mean(out.hidden.abs() @ m.get_decoder_norms().detach())
+        assert torch.isclose(out.sparsity_loss, expected, rtol=1e-5)
+        assert torch.isclose(out.loss, out.reconstruction_loss + 0.1 * out.sparsity_loss, rtol=1e-5)
+        hidden = m.encode({0: acts[0]})   # reference test_encode_combines_layers: a subset of the layers
+        assert hidden.shape == (8, 256) and torch.all(hidden >= 0)
+
+    def test_bf16_mode_against_the_oracle(self, device):
+        from whisper_sae.sae.crosscoder import CrossLayerCrosscoder
+        torch.manual_seed(2)
+        d, L, S, B, lam = 64, 4, 512, 256, 0.02
+        m = CrossLayerCrosscoder(d_model=d, n_layers=L, d_sae=S, sparsity_weight=lam, precision="bf16")
+        W = [p.detach().numpy().copy() for p in (m.W_enc, m.b_enc, m.W_dec, m.b_dec)]
+        a = [synth.activations(B, d, seed=41, stream=i, bf16=True) for i in range(L)]
+        m.to(device).train()
+        o = m({i: torch.from_numpy(a[i]).to(device) for i in range(L)})
+        o.loss.backward()
+        f = O.crosscoder_relu_forward(*W, a, lam)
+        b = O.crosscoder_relu_backward(*W, a, f, lam)
+        assert abs(float(o.loss.detach()) - float(f["loss"])) / float(f["loss"]) < 5e-3
+        assert abs(float(o.sparsity_loss) - float(f["sparsity_loss"])) / float(f["sparsity_loss"]) < 5e-3
+        # (the oracle here is plain fp32 arithmetic, not a mirror of the bf16 roundings: direction and size, not digits)
+        for n, p in (("W_enc", m.W_enc), ("b_enc", m.b_enc), ("W_dec", m.W_dec), ("b_dec", m.b_dec)):
+            got, ref = p.grad.cpu().numpy().astype(np.float64).ravel(), b[n].astype(np.float64).ravel()
+            cos = float(got @ ref / np.sqrt((got @ got) * (ref @ ref)))
+            assert cos > 0.999 and abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1) < 2e-2, (n, cos)
+
+    def test_loss_decreases(self, device):   # reference TestCrosscoderTraining.test_loss_decreases, ReLU variant
+        from whisper_sae.sae.crosscoder import CrossLayerCrosscoder
+        torch.manual_seed(0)
+        m = CrossLayerCrosscoder(d_model=32, n_layers=2, d_sae=128, sparsity_weight=0.01).to(device)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        base = torch.randn(64, 32, device=device)
+        acts = {0: base + 0.1 * torch.randn(64, 32, device=device), 1: base + 0.1 * torch.randn(64, 32, device=device)}
+        losses = []
+        for _ in range(100):
+            opt.zero_grad()
+            out = m(acts)
+            out.loss.backward()
+            opt.step()
+            m.normalize_decoder_weights()
+            losses.append(out.loss.item())
+        assert losses[-1] < losses[0] * 0.8
 
 
 @pytest.mark.gpu

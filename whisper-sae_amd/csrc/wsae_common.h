@@ -67,6 +67,7 @@ struct wsae_prof {
 struct wsae_ctx {
     wsae_prof prof;
     int D, H, K, maxB, prec, device;
+    const float* relu_l1w;  // per-feature weights of the ReLU path's L1 term (nullable; caller-owned [H] floats)
     int loss_cols;        // columns the MSE averages over (= D; transcoders with a narrower output pad D and set this)
     int cus;              // compute units of `device` (persistent-kernel grid size)
     int64_t P;            // flat pack element count

@@ -219,12 +219,15 @@ __global__ void __launch_bounds__(256) transpose_w_kernel(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256)
 relu_act_kernel(const float* __restrict__ pre, float* __restrict__ hidden, T* __restrict__ hid, T* __restrict__ hidT,
-                int B, int H, int ldT, float* __restrict__ part, int nblk) {
+                int B, int H, int ldT, float* __restrict__ part, int nblk, const float* __restrict__ l1w) {
     __shared__ float tile[64][65];
     __shared__ float red[8];
     const int h0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
     const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
     float s = 0.f, c = 0.f;
+    // per-feature weights of the L1 term (wsae_ctx_set_relu_l1_weights; the crosscoder's decoder norms), else 1
+    float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (l1w && h0 + 4 * q < H) w4 = *(const float4*)(l1w + h0 + 4 * q);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int bl = r16 + 16 * p, b = b0 + bl, h = h0 + 4 * q;
@@ -234,7 +237,7 @@ relu_act_kernel(const float* __restrict__ pre, float* __restrict__ hidden, T* __
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             *(float4*)(hidden + (int64_t)b * H + h) = v;
             store4<T>(hid + (int64_t)b * H + h, v.x, v.y, v.z, v.w);
-            s += (v.x + v.y) + (v.z + v.w);
+            s += (v.x * w4.x + v.y * w4.y) + (v.z * w4.z + v.w * w4.w);
             c += (float)((v.x > 0.f) + (v.y > 0.f) + (v.z > 0.f) + (v.w > 0.f));
         }
         tile[bl][4 * q] = v.x; tile[bl][4 * q + 1] = v.y; tile[bl][4 * q + 2] = v.z; tile[bl][4 * q + 3] = v.w;
@@ -307,10 +310,15 @@ resid_kernel(const float* __restrict__ recon, const void* __restrict__ x, const 
 template <typename T>
 __global__ void __launch_bounds__(256)
 dpre_kernel(const float* __restrict__ dh, const float* __restrict__ hidden, int B, int H, int ldT, float l1,
-            T* __restrict__ dpreT, float* __restrict__ colpart) {
+            T* __restrict__ dpreT, float* __restrict__ colpart, const float* __restrict__ l1w) {
     __shared__ float tile[64][65];
     const int h0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
     const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+    float4 l4 = make_float4(l1, l1, l1, l1);
+    if (l1w && h0 + 4 * q < H) {
+        const float4 w4 = *(const float4*)(l1w + h0 + 4 * q);
+        l4 = make_float4(l1 * w4.x, l1 * w4.y, l1 * w4.z, l1 * w4.w);
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int bl = r16 + 16 * p, b = b0 + bl, h = h0 + 4 * q;
@@ -318,10 +326,10 @@ dpre_kernel(const float* __restrict__ dh, const float* __restrict__ hidden, int 
         if (b < B && h < H) {
             const float4 d4 = *(const float4*)(dh + (int64_t)b * H + h);
             const float4 h4 = *(const float4*)(hidden + (int64_t)b * H + h);
-            v.x = h4.x > 0.f ? d4.x + l1 : 0.f;
-            v.y = h4.y > 0.f ? d4.y + l1 : 0.f;
-            v.z = h4.z > 0.f ? d4.z + l1 : 0.f;
-            v.w = h4.w > 0.f ? d4.w + l1 : 0.f;
+            v.x = h4.x > 0.f ? d4.x + l4.x : 0.f;
+            v.y = h4.y > 0.f ? d4.y + l4.y : 0.f;
+            v.z = h4.z > 0.f ? d4.z + l4.z : 0.f;
+            v.w = h4.w > 0.f ? d4.w + l4.w : 0.f;
         }
         tile[bl][4 * q] = v.x; tile[bl][4 * q + 1] = v.y; tile[bl][4 * q + 2] = v.z; tile[bl][4 * q + 3] = v.w;
     }
@@ -354,7 +362,7 @@ relu_fwd_finish_kernel(const float* __restrict__ part, int nblk_act, int nblk_re
     const float ts = block_sum(s, red), tc = block_sum(c, red), tl = block_sum(l, red);
     if (threadIdx.x == 0) {
         const float sparsity = ts / ((float)B * (float)H);
-        const float mse = tl / ((float)B * (float)D);
+        const float mse = tl / ((float)B * (float)D);  // (D here = the ctx's loss_cols)
         scal[0] = sparsity;
         scal[1] = mse;
         if (sparsity_out) *sparsity_out = sparsity;
@@ -471,7 +479,7 @@ int forward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     const T* wdt = sizeof(T) == 2 ? (const T*)ctx->WdT_bf16 : (const T*)(params + ctx->off[1]);
     transpose_w_kernel<T><<<dim3(ceil_div(H, 64), ceil_div(D, 64)), 256, 0, st>>>(wdt, (T*)ws.wd_nt, H, D);
     dim3 ga(ceil_div(H, 64), ceil_div(ldT, 64));
-    relu_act_kernel<T><<<ga, 256, 0, st>>>(ctx->pre, hidden, (T*)ws.hid, (T*)ws.hidT, B, H, ldT, ws.part, ws.nblk);
+    relu_act_kernel<T><<<ga, 256, 0, st>>>(ctx->pre, hidden, (T*)ws.hid, (T*)ws.hidT, B, H, ldT, ws.part, ws.nblk, ctx->relu_l1w);
     if (fp8) {
         quant_rows(st, ws.hid, WSAE_DT_BF16, nullptr, B, H, ws.hidq, ws.sh);
         quant_rows(st, ws.wd_nt, WSAE_DT_BF16, nullptr, D, H, ws.wdq, ws.swd);
@@ -487,7 +495,7 @@ int forward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     else
         resid_kernel<T, WSAE_DT_BF16, false><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, 0.f, nullptr, nullptr, nullptr,
                                                                 ws.part + 2 * ws.nblk);
-    relu_fwd_finish_kernel<<<1, 256, 0, st>>>(ws.part, (int)(ga.x * ga.y), (int)(gr.x * gr.y), ws.nblk, B, D, H, weight,
+    relu_fwd_finish_kernel<<<1, 256, 0, st>>>(ws.part, (int)(ga.x * ga.y), (int)(gr.x * gr.y), ws.nblk, B, ctx->loss_cols, H, weight,
                                               stats, sparsity_out, ws.scal);
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;
@@ -499,7 +507,7 @@ int backward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
     const int D = ctx->D, H = ctx->H;
     const int ldT = (B + 127) / 128 * 128;
     const ReluWs ws = host_ws(ctx);
-    const float scale = 2.0f / ((float)B * (float)D);
+    const float scale = 2.0f / ((float)B * (float)ctx->loss_cols);  // (the crosscoder sums per-layer means: loss_cols = d_model)
     dim3 gr(ceil_div(D, 64), ceil_div(ldT, 64));
     // g (row-major, into the staging buffer xb: the encoder GEMM is done with it), gT, db_d partials
     if (x_dtype == WSAE_DT_F32)
@@ -511,7 +519,7 @@ int backward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
     const T* wdt = sizeof(T) == 2 ? (const T*)ctx->WdT_bf16 : (const T*)(params + ctx->off[1]);
     gemm_nt<T>(ctx, st, ctx->xb, D, wdt, D, nullptr, ctx->pre, H, B, H, D, 1, 0);  // dh = g W_d  [B][H]
     dim3 ga(ceil_div(H, 64), ceil_div(ldT, 64));
-    dpre_kernel<T><<<ga, 256, 0, st>>>(ctx->pre, hidden, B, H, ldT, weight / ((float)B * (float)H), (T*)ws.dpreT, ws.colpart);
+    dpre_kernel<T><<<ga, 256, 0, st>>>(ctx->pre, hidden, B, H, ldT, weight / ((float)B * (float)H), (T*)ws.dpreT, ws.colpart, ctx->relu_l1w);
     // split-K contractions over the batch into the slabs: [z][ dW_e (H*D) | dW_dT (H*D) ]
     const int nz = min(WSAE_WGRAD_MAX_SPLIT, max(1, ldT / 512));
     const int64_t hd = (int64_t)H * D, slab_stride = 2 * hd;
@@ -540,6 +548,12 @@ extern "C" int wsae_ctx_set_relu_fp8(wsae_ctx* ctx, int32_t on) {
 extern "C" int wsae_ctx_reserve_relu(wsae_ctx* ctx) {
     WSAE_REQUIRE(ctx, "wsae_ctx_reserve_relu: null ctx");
     return reserve_ws(ctx);
+}
+
+extern "C" int wsae_ctx_set_relu_l1_weights(wsae_ctx* ctx, const float* weights) {
+    WSAE_REQUIRE(ctx, "wsae_ctx_set_relu_l1_weights: null ctx");
+    ctx->relu_l1w = weights;
+    return WSAE_OK;
 }
 
 extern "C" int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,

@@ -21,9 +21,13 @@ backward) on one ``[B, n_layers * d_model]`` tensor, through the same autograd n
 limits apply to the concatenated width: ``n_layers * d_model <= 2048`` (Whisper-tiny x 4 layers = 1536, -base x 4 =
 2048), ``k <= 128``.
 
-The ReLU base class keeps the reference's constructor, parameters, initialisation and analysis helpers (decoder norms,
-per-layer norms, cross-layer mask, dead-feature clock); its decoder-norm-weighted L1 objective (:213-217) has no HIP
-path and ``encode`` / ``forward`` raise ``WsaeError`` for ``activation="relu"`` instead of falling back to PyTorch.
+The ReLU variant (``CrossLayerCrosscoder``, ``activation="relu"``) runs on the ReLU-SAE kernels the same way
+(``wsae_relu_forward`` / ``wsae_relu_backward`` on the concatenated layers, ``loss_cols = d_model``).  Its sparsity term is
+the decoder-norm-weighted L1 of the crosscoder paper (:213-217), ``mean_b sum_s |h_bs| n_s`` with ``n_s`` the norm of
+feature ``s``'s flattened decoder row: the kernels take ``n`` as per-feature weights of their L1 term
+(``wsae_ctx_set_relu_l1_weights``) with ``sparsity_weight * d_sae`` as the coefficient (their term is a mean over
+``B * d_sae``).  ``n`` also depends on ``W_dec``; that part of the gradient, ``sparsity_weight * mean_b|h_bs| * W_dec[s] /
+n_s``, is a ``[d_sae, n_layers * d_model]`` element-wise expression added in the backward (torch).
 """
 
 from __future__ import annotations
@@ -36,7 +40,8 @@ from torch import Tensor, nn
 from .. import _native as N
 from .engine import SAEEngine, require_device_tensor
 from .model import _precision_code
-from .transcoder import _SparsePath, _TranscoderBase
+from .engine import _dtype_code
+from .transcoder import _SparsePath, _TranscoderBase, _as_rows
 
 
 class CrosscoderOutput(NamedTuple):
@@ -49,6 +54,82 @@ class CrosscoderOutput(NamedTuple):
     sparsity_loss: Tensor
     l0: Tensor
     per_layer_loss: Dict[int, Tensor]
+
+
+class _ReLUCrossPath(torch.autograd.Function):
+    """wsae_relu_forward (-> wsae_relu_backward) on the concatenated layers with the decoder norms as per-feature L1
+    weights; gradients of ``loss`` with respect to the four parameters (the norm term of ``W_dec`` included)."""
+
+    @staticmethod
+    def forward(ctx, xc, w_e, b_e, w_d, b_d, module, prec):
+        eng: SAEEngine = module._engine
+        x2 = _as_rows(xc, module.input_dim, eng.D)
+        B = x2.shape[0]
+        handle = eng.prepare(prec, B, force=True)
+        eng.reserve_relu(handle)
+        lib, st = eng.lib, eng.stream()
+        norms = module.get_decoder_norms().detach().float().contiguous()
+        lam = float(module.sparsity_weight)
+        N.check(lib.wsae_ctx_set_relu_fp8(handle, 0), "wsae_ctx_set_relu_fp8")
+        N.check(lib.wsae_ctx_set_loss_cols(handle, module.d_model), "wsae_ctx_set_loss_cols")
+        N.check(lib.wsae_ctx_set_relu_l1_weights(handle, norms.data_ptr()), "wsae_ctx_set_relu_l1_weights")
+        hidden = torch.empty(B, eng.H, dtype=torch.float32, device=eng.device)
+        recon = torch.empty(B, eng.D, dtype=torch.float32, device=eng.device)
+        wmean = torch.empty((), dtype=torch.float32, device=eng.device)  # sum_b sum_s n_s |h| / (B H)
+        try:
+            N.check(lib.wsae_relu_forward(handle, eng.pack.data_ptr(), x2.data_ptr(), _dtype_code(x2), 0, B, lam * eng.H,
+                                          hidden.data_ptr(), recon.data_ptr(), eng.stats.data_ptr(), wmean.data_ptr(), st),
+                    "wsae_relu_forward")
+        finally:  # the weights are this call's: leave the ctx as the ReLU SAE expects it
+            lib.wsae_ctx_set_relu_l1_weights(handle, 0)
+            lib.wsae_ctx_set_loss_cols(handle, eng.D)
+        sf = eng.stats_f32()
+        loss, l0 = sf[0].clone(), sf[1].clone()
+        sparsity = wmean * float(eng.H)  # mean_b sum_s n_s |h_bs|  (reference crosscoder.py:217)
+        eng.generation += 1
+        ctx.module, ctx.prec, ctx.gen, ctx.B, ctx.lam = module, prec, eng.generation, B, lam
+        ctx.save_for_backward(x2, hidden, recon, norms)
+        ctx.set_materialize_grads(False)
+        recon_out = recon[:, :module.input_dim]
+        ctx.mark_non_differentiable(recon_out, hidden, sparsity, l0)
+        return recon_out, hidden, loss, sparsity, l0
+
+    @staticmethod
+    def backward(ctx, g_recon, g_hidden, g_loss, g_sparsity, g_l0):
+        if g_loss is None:
+            return (None,) * 7
+        module, prec, B, lam = ctx.module, ctx.prec, ctx.B, ctx.lam
+        eng: SAEEngine = module._engine
+        x2, hidden, recon, norms = ctx.saved_tensors
+        handle = eng.prepare(prec, B, force=True)
+        eng.reserve_relu(handle)
+        lib, st, pk, xd = eng.lib, eng.stream(), eng.pack.data_ptr(), _dtype_code(x2)
+        N.check(lib.wsae_ctx_set_relu_fp8(handle, 0), "wsae_ctx_set_relu_fp8")
+        N.check(lib.wsae_ctx_set_loss_cols(handle, module.d_model), "wsae_ctx_set_loss_cols")
+        N.check(lib.wsae_ctx_set_relu_l1_weights(handle, norms.data_ptr()), "wsae_ctx_set_relu_l1_weights")
+        grads = torch.empty(eng.P, dtype=torch.float32, device=eng.device)
+        try:
+            if eng.generation != ctx.gen:  # another call reused the ctx workspace since: restage this batch
+                h2, r2 = torch.empty_like(hidden), torch.empty_like(recon)
+                N.check(lib.wsae_relu_forward(handle, pk, x2.data_ptr(), xd, 0, B, lam * eng.H, h2.data_ptr(), r2.data_ptr(), 0, 0,
+                                              st), "wsae_relu_forward")
+                eng.generation += 1
+            N.check(lib.wsae_relu_backward(handle, pk, x2.data_ptr(), xd, 0, B, lam * eng.H, hidden.data_ptr(),
+                                           recon.data_ptr(), grads.data_ptr(), st), "wsae_relu_backward")
+        finally:
+            lib.wsae_ctx_set_relu_l1_weights(handle, 0)
+            lib.wsae_ctx_set_loss_cols(handle, eng.D)
+        need = ctx.needs_input_grad
+        if need[3] and lam != 0.0:
+            # d/dW_dec of lam * mean_b sum_s |h_bs| n_s through n_s = ||W_dec[s]||:  lam * mean_b|h_bs| * W_dec[s] / n_s
+            col = hidden.sum(dim=0) * (lam / B)                       # hidden >= 0
+            wd = module._sliced("decoder.weight").detach().reshape(module.d_sae, -1)
+            gview = eng.view("decoder.weight", grads)                # [Dp, H] view of the pack layout
+            gview[:module.input_dim, :].add_((wd * (col / norms.clamp_min(1e-30)).unsqueeze(1)).t())
+        grads.mul_(g_loss)
+        gv = lambda name, on: module._sliced(name, grads) if on else None  # noqa: E731
+        return (None, gv("encoder.weight", need[1]), gv("encoder.bias", need[2]), gv("decoder.weight", need[3]),
+                gv("decoder.bias", need[4]), None, None)
 
 
 class CrossLayerCrosscoder(_TranscoderBase):
@@ -140,19 +221,23 @@ class CrossLayerCrosscoder(_TranscoderBase):
         d = self.d_model
         return {li: flat[:, i * d:(i + 1) * d] for i, li in enumerate(self.layer_indices)}
 
-    def _no_relu_path(self):
-        raise N.WsaeError(
-            "CrossLayerCrosscoder(activation='relu'): the decoder-norm-weighted L1 objective (reference "
-            "crosscoder.py:213-217) has no HIP path in this build and there is no PyTorch fallback; use "
-            "TopKCrossLayerCrosscoder / create_crosscoder(use_topk=True).")
-
     # -- reference API -----------------------------------------------------------------------------------
     def get_decoder_norms(self) -> Tensor:
         """L2 norm of each feature's decoder row over all layers, ``[d_sae]`` (reference crosscoder.py:124-131)."""
         return torch.norm(self.W_dec.reshape(self.d_sae, -1), dim=1)
 
+    def _relu(self, xc: Tensor):
+        if self.activation != "relu":
+            raise ValueError(f"Unknown activation: {self.activation}")  # as the reference (crosscoder.py:167)
+        self._check_width()
+        self.bind()
+        return _ReLUCrossPath.apply(xc, self.W_enc, self.b_enc, self.W_dec, self.b_dec, self,
+                                    _precision_code(self.precision))
+
+    @torch.no_grad()
     def encode(self, layer_activations: Dict[int, Tensor]) -> Tensor:
-        self._no_relu_path()
+        """``relu(sum_l acts_l @ W_enc[l] + b_enc)`` of the layers given (reference crosscoder.py:142-169)."""
+        return self._relu(self._gather(layer_activations, need_all=False))[1]
 
     @torch.no_grad()
     def decode(self, hidden: Tensor) -> Dict[int, Tensor]:
@@ -161,7 +246,17 @@ class CrossLayerCrosscoder(_TranscoderBase):
         return self._split(_TranscoderBase.decode(self, hidden))
 
     def forward(self, layer_activations: Dict[int, Tensor]) -> CrosscoderOutput:
-        self._no_relu_path()
+        """Reference crosscoder.py:188-235: sum of per-layer MSEs + ``sparsity_weight`` x decoder-norm-weighted L1."""
+        xc = self._gather(layer_activations, need_all=True)
+        recon, hidden, loss, sparsity, l0 = self._relu(xc)
+        with torch.no_grad():
+            err = (recon - xc.detach().float()).square_().view(-1, self.n_layers, self.d_model).mean(dim=(0, 2))
+            if self.training:  # the dead-feature clock (crosscoder.py:237-242; the ReLU kernels keep none)
+                self.step_count += 1
+                self.feature_last_activated[(hidden > 0).any(dim=0)] = self.step_count
+        per_layer = {li: err[i] for i, li in enumerate(self.layer_indices)}
+        return CrosscoderOutput(reconstructed=self._split(recon), hidden=hidden, loss=loss, reconstruction_loss=err.sum(),
+                                sparsity_loss=sparsity, l0=l0, per_layer_loss=per_layer)
 
     def get_feature_layer_norms(self) -> Tensor:
         """``[d_sae, n_layers]`` decoder norm of every feature in every layer (reference crosscoder.py:251-261)."""
