@@ -83,9 +83,9 @@ __device__ __forceinline__ void wave_sort_desc(KT (&key)[NPL], int lane) {
                     const bool desc = (p & size) == 0;
                     const bool lower = (p & stride) == 0;
                     const bool keep_max = (lower == desc);
-                    const KT mx = key[i] > other ? key[i] : other;
-                    const KT mn = key[i] > other ? other : key[i];
-                    key[i] = keep_max ? mx : mn;
+                    // one select per exchange: keep the own key when (own > other) says what this position wants, else
+                    // take the partner's (max and min computed separately and selected afterwards cost three selects)
+                    key[i] = ((key[i] > other) == keep_max) ? key[i] : other;
                 }
             } else {
 #pragma unroll
@@ -95,9 +95,9 @@ __device__ __forceinline__ void wave_sort_desc(KT (&key)[NPL], int lane) {
                         const int p = lane * NPL + i;
                         const bool desc = (p & size) == 0;
                         const KT a = key[i], b = key[j];
-                        const KT mx = a > b ? a : b, mn = a > b ? b : a;
-                        key[i] = desc ? mx : mn;
-                        key[j] = desc ? mn : mx;
+                        const bool swap = (a > b) != desc;
+                        key[i] = swap ? b : a;
+                        key[j] = swap ? a : b;
                     }
                 }
             }
