@@ -130,19 +130,62 @@ struct wsae_ctx {
 
 #define WSAE_WAVE 64
 
+// value of lane (l ^ M) without the LDS pipe (__shfl_xor = ds_bpermute_b32, ~100+ cycles of latency each, and a
+// bitonic sort of 64 keys chains 21 of them per 32-bit half): DPP for M = 1, 2, 4, 8, v_permlane16/32_swap for
+// M = 16, 32 (profiles/tools/lane_ops_probe.hip prints what each control delivers).  Every DPP move runs with
+// all lanes active and the select comes after it: a DPP source lane that is masked off reads as invalid.
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t x, int lane) {
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) {
+        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0xF, false);  // row_shl:4 = lane l + 4
+        const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);  // row_shr:4 = lane l - 4
+        return (lane & 4) ? dn : up;
+    } else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);  // row_ror:8
+    else if constexpr (M == 16) {
+        // swap16(a = x, b = x): a' = rows [x0, x0, x2, x2], b' = rows [x1, x1, x3, x3]
+        const auto r = __builtin_amdgcn_permlane16_swap((int)x, (int)x, false, false);
+        return (uint32_t)((lane & 16) ? r[0] : r[1]);
+    } else {
+        static_assert(M == 32, "lane_xor_u32: M must be a power of two <= 32");
+        // swap32(a = x, b = x): a' = [x.lo, x.lo], b' = [x.hi, x.hi]
+        const auto r = __builtin_amdgcn_permlane32_swap((int)x, (int)x, false, false);
+        return (uint32_t)((lane & 32) ? r[0] : r[1]);
+    }
+}
+
+// butterfly reductions over the 64 lanes (every lane gets the result; pair order 32, 16, .., 1 - the order the
+// __shfl_xor form had, so the sums are bit-identical to it) on the lane exchanges above: six ds_bpermute round trips
+// of ~100+ cycles each were most of a wave's tail in the one-round kernels (update_rows, grad_finish, the decode epilogue)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63;
+    v += __uint_as_float(lane_xor_u32<32>(__float_as_uint(v), lane));
+    v += __uint_as_float(lane_xor_u32<16>(__float_as_uint(v), lane));
+    v += __uint_as_float(lane_xor_u32<8>(__float_as_uint(v), lane));
+    v += __uint_as_float(lane_xor_u32<4>(__float_as_uint(v), lane));
+    v += __uint_as_float(lane_xor_u32<2>(__float_as_uint(v), lane));
+    v += __uint_as_float(lane_xor_u32<1>(__float_as_uint(v), lane));
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const int lane = threadIdx.x & 63;
+    v = fmaxf(v, __uint_as_float(lane_xor_u32<32>(__float_as_uint(v), lane)));
+    v = fmaxf(v, __uint_as_float(lane_xor_u32<16>(__float_as_uint(v), lane)));
+    v = fmaxf(v, __uint_as_float(lane_xor_u32<8>(__float_as_uint(v), lane)));
+    v = fmaxf(v, __uint_as_float(lane_xor_u32<4>(__float_as_uint(v), lane)));
+    v = fmaxf(v, __uint_as_float(lane_xor_u32<2>(__float_as_uint(v), lane)));
+    v = fmaxf(v, __uint_as_float(lane_xor_u32<1>(__float_as_uint(v), lane)));
     return v;
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63;
+    v += (int)lane_xor_u32<32>((uint32_t)v, lane);
+    v += (int)lane_xor_u32<16>((uint32_t)v, lane);
+    v += (int)lane_xor_u32<8>((uint32_t)v, lane);
+    v += (int)lane_xor_u32<4>((uint32_t)v, lane);
+    v += (int)lane_xor_u32<2>((uint32_t)v, lane);
+    v += (int)lane_xor_u32<1>((uint32_t)v, lane);
     return v;
 }
 

@@ -19,31 +19,7 @@ __device__ __forceinline__ uint32_t f32_ord(float f) {
 __device__ __forceinline__ float ord_f32(uint32_t o) {
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
 }
-// value of lane (l ^ M) without the LDS pipe (__shfl_xor = ds_bpermute_b32, ~100+ cycles of latency each, and a
-// bitonic sort of 64 keys chains 21 of them per 32-bit half): DPP for M = 1, 2, 4, 8, v_permlane16/32_swap for
-// M = 16, 32 (profiles/tools/lane_ops_probe.hip prints what each control delivers).  Every DPP move runs with
-// all lanes active and the select comes after it: a DPP source lane that is masked off reads as invalid.
-template <int M>
-__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t x, int lane) {
-    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
-    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    else if constexpr (M == 4) {
-        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0xF, false);  // row_shl:4 = lane l + 4
-        const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);  // row_shr:4 = lane l - 4
-        return (lane & 4) ? dn : up;
-    } else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);  // row_ror:8
-    else if constexpr (M == 16) {
-        // swap16(a = x, b = x): a' = rows [x0, x0, x2, x2], b' = rows [x1, x1, x3, x3]
-        const auto r = __builtin_amdgcn_permlane16_swap((int)x, (int)x, false, false);
-        return (uint32_t)((lane & 16) ? r[0] : r[1]);
-    } else {
-        static_assert(M == 32, "lane_xor_u32: M must be a power of two <= 32");
-        // swap32(a = x, b = x): a' = [x.lo, x.lo], b' = [x.hi, x.hi]
-        const auto r = __builtin_amdgcn_permlane32_swap((int)x, (int)x, false, false);
-        return (uint32_t)((lane & 32) ? r[0] : r[1]);
-    }
-}
-
+// (lane_xor_u32<M>: wsae_common.h)
 template <int M>
 __device__ __forceinline__ uint64_t lane_xor_u64(uint64_t v, int lane) {
     return ((uint64_t)lane_xor_u32<M>((uint32_t)(v >> 32), lane) << 32) | lane_xor_u32<M>((uint32_t)v, lane);
