@@ -211,11 +211,12 @@ __device__ __forceinline__ void topk_strips_row(const float* __restrict__ row, c
     if constexpr (NTOP == 1) {
         uint32_t mk[1] = {f32_ord(m)};
         wave_sort_desc<1, uint32_t>(mk, lane);
-        thi = __shfl(mk[0], K - 1, 64);
+        thi = (uint32_t)__builtin_amdgcn_readlane((int)mk[0], K - 1);  // (K is wave-uniform: v_readlane, not an LDS round trip)
     } else {
         uint32_t mk[2] = {f32_ord(m), f32_ord(m2)};
         wave_sort_desc<2, uint32_t>(mk, lane);  // position p of the descending order sits in lane p / 2, slot p % 2
-        const uint32_t lo = __shfl(mk[0], (K - 1) >> 1, 64), hi = __shfl(mk[1], (K - 1) >> 1, 64);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)mk[0], (K - 1) >> 1);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)mk[1], (K - 1) >> 1);
         thi = ((K - 1) & 1) ? hi : lo;
     }
 

@@ -545,8 +545,8 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
                 const float v = (j < nr && sp < nsplit && r0 + j < H) ? dbe_slab[(int64_t)sp * H + r0 + j] : 0.f;
 #pragma unroll
                 for (int s2 = 0; s2 < WSAE_WGRAD_MAX_SPLIT; ++s2) {
-                    be[0] += __shfl(v, s2, 64);
-                    be[1] += __shfl(v, 8 + s2, 64);
+                    be[0] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), s2));
+                    be[1] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 8 + s2));
                 }
                 if (lane == 0) {
 #pragma unroll
