@@ -136,6 +136,8 @@ decode_mfma_kernel(const bf16_t* __restrict__ WdT, const float* __restrict__ bd,
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, grp = lane >> 4;
+    // which of the three bf16 pieces of a value this lane's A row carries (rows 0..2 of the 16-row tile; the rest zero)
+    const uint32_t piece_mask[3] = {n == 0 ? 0xFFFFFFFFu : 0u, n == 1 ? 0xFFFFFFFFu : 0u, n == 2 ? 0xFFFFFFFFu : 0u};
     char* wbase = smem + wave * WAVE_BYTES;
     char* slot0 = wbase;
     char* code = wbase + 2 * SLOT;                            // [2 buffers][vals KP f32 | idx KP i32]
@@ -259,20 +261,35 @@ decode_mfma_kernel(const bf16_t* __restrict__ WdT, const float* __restrict__ bd,
             }
         }
         // ---- A fragments of pass 1: rows 0..2 = the three bf16 pieces of relu(v), k = feature slot ----
+        // (branch-free: the three pieces are computed in packed pairs by every lane and picked with lane-constant bit
+        // masks - written as n == 0 ? hi : n == 1 ? lo : .. hipcc nested two divergent branches around every element)
         bf16x8 a1[KS];
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
             const float4 v0 = *(const float4*)(vs + 32 * q + 8 * grp), v1 = *(const float4*)(vs + 32 * q + 8 * grp + 4);
             const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            uint32_t w4[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = fmaxf(vv[e], 0.f);  // negative winners decode as zero (model.py:116)
-                const bf16_t hi = (bf16_t)v;
-                const float r1 = v - (float)hi;
-                const bf16_t lo = (bf16_t)r1;
-                const bf16_t lo2 = (bf16_t)(r1 - (float)lo);
-                a1[q][e] = n == 0 ? hi : n == 1 ? lo : n == 2 ? lo2 : (bf16_t)0.f;
+            for (int p2 = 0; p2 < 4; ++p2) {
+                // negative winners decode as zero (model.py:116): clamp to [0, inf) in one instruction
+                const float a = __builtin_amdgcn_fmed3f(vv[2 * p2], 0.f, INFINITY);
+                const float b = __builtin_amdgcn_fmed3f(vv[2 * p2 + 1], 0.f, INFINITY);
+                bf16x2 h2;
+                h2[0] = (bf16_t)a; h2[1] = (bf16_t)b;
+                const uint32_t hb = __builtin_bit_cast(uint32_t, h2);
+                const float ra = a - __uint_as_float(hb << 16), rb = b - __uint_as_float(hb & 0xFFFF0000u);
+                bf16x2 l2;
+                l2[0] = (bf16_t)ra; l2[1] = (bf16_t)rb;
+                const uint32_t lb = __builtin_bit_cast(uint32_t, l2);
+                const float sa = ra - __uint_as_float(lb << 16), sb = rb - __uint_as_float(lb & 0xFFFF0000u);
+                bf16x2 t2;
+                t2[0] = (bf16_t)sa; t2[1] = (bf16_t)sb;
+                const uint32_t tb = __builtin_bit_cast(uint32_t, t2);
+                w4[p2] = (hb & piece_mask[0]) | (lb & piece_mask[1]) | (tb & piece_mask[2]);
             }
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 wv = {w4[0], w4[1], w4[2], w4[3]};
+            a1[q] = __builtin_bit_cast(bf16x8, wv);
         }
         DM_T(1)
         // ---- the next row's code and gather sources (its first pieces are issued from inside this row's loop) ----
