@@ -29,26 +29,15 @@ for _p in (str(ROOT), str(ROOT / "whisper-sae_amd")):
 D_MODEL, HIDDEN, TOPK = 384, 3072, 32
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"  # written by profiles/tools/profile_step.sh on this build
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"  # written by profiles/tools/profile_step.sh on this build
 
 
-def cpu_baseline(batch: int, budget_s: float = 20.0) -> dict:
-    """Reference-semantics CPU train step (oracle/torch_step.py, kind "port") on the host cores."""
-    import numpy as np
+def _cpu_leg(batch: int, budget_s: float, max_steps: int, cores: int) -> tuple:
     import torch
 
     from oracle import synth
     from oracle.torch_step import TorchCPUStep
 
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
-    # a 1-GPU box gives this process a 16-core share of the host; oversubscribing the 256 visible
-    # hardware threads made torch ~10x slower.  WSAE_CPU_THREADS overrides.
-    cores = int(os.environ.get("WSAE_CPU_THREADS", min(cores, 16)))
-    torch.set_num_threads(cores)
     w = synth.sae_weights(D_MODEL, HIDDEN, seed=42, bf16=False)
     step = TorchCPUStep(w, TOPK, lr=1e-4, weight_decay=0.0, max_norm=1.0)
     x = torch.from_numpy(synth.activations(batch, D_MODEL, seed=42, stream=0, bf16=False))
@@ -59,11 +48,78 @@ def cpu_baseline(batch: int, budget_s: float = 20.0) -> dict:
         step.step(x)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 50:
+        if el > budget_s or n >= max_steps:
             break
+    return n, el
+
+
+def cpu_baseline(batch: int, budget_s: float = 16.0) -> dict:
+    """Reference-semantics CPU train step (oracle/torch_step.py, kind "port") on the host cores: the headline batch
+    (``value``) and, as SURVEY.md section 8 row D asks, the reference YAMLs' own B = 128 and B = 4096 beside it."""
+    import torch
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    # a 1-GPU box gives this process a 16-core share of the host; oversubscribing the 256 visible
+    # hardware threads made torch ~10x slower.  WSAE_CPU_THREADS overrides.
+    cores = int(os.environ.get("WSAE_CPU_THREADS", min(cores, 16)))
+    torch.set_num_threads(cores)
+    n, el = _cpu_leg(batch, budget_s, 50, cores)
+    others = []
+    for b, budget, cap in ((128, 3.0, 400), (4096, 5.0, 60)):
+        if b == batch:
+            continue
+        nb, elb = _cpu_leg(b, budget, cap, cores)
+        others.append({"batch": b, "value": b * nb / elb, "steps": nb, "seconds": elb})
     return {"value": batch * n / el, "unit": "activations/s", "cores": cores, "kind": "port",
             "sample": f"{n} train steps of B={batch} (384->3072, k=32, fp32, torch {torch.__version__} CPU, "
-                      f"{el:.1f} s); oracle/torch_step.py restates training.py:161-217"}
+                      f"{el:.1f} s); oracle/torch_step.py restates training.py:161-217",
+            "other_batches": others}
+
+
+# Algorithmic work per launch of the step's kernels at batch B (DESIGN.md section 4): flops on MFMA and the bytes the
+# kernel cannot avoid moving given what the step hands it (inputs read once, outputs written once).
+def kernel_work(name: str, B: int, D: int, H: int, K: int) -> dict:
+    P = 2 * D * H + H + 2 * D
+    if name.startswith("encode_gemm"):
+        return {"flops": 2.0 * B * D * H, "bytes": 2.0 * B * D + 2.0 * H * D + 4.0 * B * H + 4.0 * B * H / 16,
+                "bound": "hbm-store", "what": "x rows + bf16 W_e in, fp32 pre [B,H] + strip maxima out"}
+    if name.startswith("wgrad_reduce") or name.startswith("grad_finish"):
+        return {"flops": 0.0, "bytes": 4.0 * 8 * 2 * H * D + 4.0 * P, "bound": "hbm", "what": "8 slabs in, gradient pack out"}
+    if name.startswith("wgrad"):
+        return {"flops": 2 * (2.0 * H * D * B), "bytes": 2 * 2.0 * B * D + 12.0 * B * K + 4.0 * 8 * 2 * H * D,
+                "bound": "mfma", "what": "g and x rows + bucketed code in, 8 split-K slabs out"}
+    if name.startswith("decode"):
+        return {"flops": 2 * (2.0 * B * K * D), "bytes": 2.0 * B * D + 8.0 * B * K + 2.0 * B * D + 4.0 * B * K + 2.0 * H * D,
+                "bound": "hbm", "what": "x rows + code in, bf16 g + dpre out, bf16 W_d (L2-resident gathers: 2 B K D bytes)"}
+    if name.startswith("topk"):
+        return {"flops": 0.0, "bytes": 4.0 * B * H / 16 + 4.0 * B * H * 0.22 + 8.0 * B * K, "bound": "hbm",
+                "what": "strip maxima + the ~22 % of pre strips at or above the row threshold in, code out"}
+    if name.startswith("bucket"):
+        return {"flops": 0.0, "bytes": 2 * 12.0 * B * K, "bound": "hbm", "what": "code in, bucketed code out"}
+    if name.startswith("adamw") or name.startswith("update_rows"):
+        return {"flops": 0.0, "bytes": 28.0 * P + 2.0 * 2 * H * D, "bound": "hbm", "what": "p, g, m, v in; p, m, v + bf16 shadows out"}
+    return {"flops": 0.0, "bytes": 0.0, "bound": "hbm", "what": ""}
+
+
+def roofline_object(name: str, n: int, ms: float, B: int, traffic_rec) -> dict:
+    w = kernel_work(name, B, D_MODEL, HIDDEN, TOPK)
+    t = ms / n * 1e-3
+    tf = w["flops"] / t / 1e12
+    gbs = w["bytes"] / t / 1e9
+    mfma = w["bound"] == "mfma"
+    out = {"bound": w["bound"], "kernel": name, "achieved": tf if mfma else gbs,
+           "peak": BF16_DENSE_PEAK_TFLOPS if mfma else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma else "GB/s",
+           "frac": (tf / BF16_DENSE_PEAK_TFLOPS) if mfma else (gbs / HBM_PEAK_GBS),
+           "avg_launch_ms": ms / n, "launches": n, "flops_per_launch": w["flops"], "algorithmic_bytes_per_launch": w["bytes"],
+           "algorithmic_bytes_are": w["what"], "mfma_frac": tf / BF16_DENSE_PEAK_TFLOPS, "hbm_frac": gbs / HBM_PEAK_GBS,
+           "traffic": None, "traffic_source": None}
+    if traffic_rec:
+        out["traffic"], out["traffic_source"] = traffic_rec
+    return out
 
 
 def main() -> None:
@@ -152,9 +208,22 @@ def main() -> None:
     eng = model._engine
     prec = N.PREC_BF16 if args.precision == "bf16" else N.PREC_FP32
     handle = eng.ctx(prec, B)
-    # events around the dominant kernel only (two event records per step) inside the timed region
-    dominant = N.lib().wsae_kernel_name  # noqa: F841
-    kid = -1 if args.profile_all else N.K_WGRAD
+    # Which kernel is the dominant one is MEASURED, not assumed: an untimed probe window with HIP events around every
+    # launch (recorded by the library on the launch stream) ranks the step's kernels by average duration; the timed
+    # windows then carry events around that kernel only (two event records per step).
+    probe = {}
+    if not args.profile_all:
+        n_probe = 24
+        N.check(N.lib().wsae_profile_enable(handle, -1, n_probe), "wsae_profile_enable")
+        for _ in range(n_probe):
+            trainer.train_step(next(it))
+        probe = N.profile_read(handle)
+        N.check(N.lib().wsae_profile_disable(handle), "wsae_profile_disable")
+    kid = -1
+    dominant = None
+    if probe:
+        dominant = max(probe, key=lambda k: probe[k][1] / max(probe[k][0], 1))
+        kid = next(k for k in range(N.KERNEL_COUNT) if N.lib().wsae_kernel_name(k).decode() == dominant)
     N.check(N.lib().wsae_profile_enable(handle, kid, args.steps * args.windows), "wsae_profile_enable")
 
     # windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both
@@ -182,31 +251,47 @@ def main() -> None:
         value = world * B * args.steps / elapsed
         # flop per activation: the reference's 2 fwd + 4 bwd dense GEMMs (TopK), 2 + 3 without dL/dx (ReLU, row A12)
         f_dense = (10 if args.relu else 12) * D_MODEL * HIDDEN
-        # roofline of the dominant kernel: the two weight-gradient contractions, [H,B]x[B,D] each
-        n_w, ms_w = prof.get("wgrad", (0, 0.0))
-        roof = None
-        if n_w and not args.dims and not args.relu:
-            flops_per_launch = 2 * (2.0 * HIDDEN * D_MODEL * B)
-            # HBM bytes per launch of this kernel: the FETCH_SIZE / WRITE_SIZE PMC passes of this build committed
-            # under profiles/ (profiles/tools/profile_step.sh; PMC cannot be collected inside a timed run).  Only
-            # valid at the configuration the passes were run at.
-            traffic, traffic_src = None, None
-            pmc = ROOT / "profiles" / PMC_TRAFFIC_FILE
-            if B == 16384 and args.precision == "bf16" and pmc.exists():
-                rec = json.loads(pmc.read_text())["kernels"].get("wgrad2_kernel")
-                if rec:
-                    traffic, traffic_src = rec["hbm_bytes"], f"profiles/{PMC_TRAFFIC_FILE} (2 x FETCH_SIZE + WRITE_SIZE, median per launch)"
-            achieved = flops_per_launch / (ms_w / n_w * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "wgrad2_kernel<bf16>", "achieved": achieved,
-                    "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
-                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": ms_w / n_w, "launches": n_w,
-                    "flops_per_launch": flops_per_launch,
-                    "step_dense_equiv_tflops": value * f_dense / 1e12,
-                    "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS,
-                    # what the step really issues on MFMA: encoder GEMM 2*D*H + the two weight-gradient
-                    # contractions 4*D*H per activation (the decode and dpre products are sparse, k rows each)
-                    "f_exec_per_activation": 6 * D_MODEL * HIDDEN,
-                    "step_mfma_exec_frac": value * 6 * D_MODEL * HIDDEN / 1e12 / BF16_DENSE_PEAK_TFLOPS}
+        # roofline of the dominant kernel (by measured time), HIP-event duration inside the timed windows; the
+        # weight-gradient contraction - the MFMA-bound kernel of the step - keeps an object of its own from the probe window
+        roof, roof_wgrad = None, None
+        headline = not args.dims and not args.relu
+        pmc_k = {}
+        pmc = ROOT / "profiles" / PMC_TRAFFIC_FILE
+        if headline and B == 16384 and args.precision == "bf16" and pmc.exists():
+            pmc_k = json.loads(pmc.read_text())["kernels"]
+
+        pmc_names = {"encode_gemm": "encode_gemm256d_kernel", "topk": "topk_strips_kernel", "decode": "decode_mfma_kernel",
+                     "bucket": "bucket_kernel", "wgrad": "wgrad2_kernel", "wgrad_reduce": "grad_finish_kernel",
+                     "adamw": "update_rows_kernel"}
+
+        def traffic_of(name):
+            # HBM bytes per launch: the FETCH_SIZE / WRITE_SIZE PMC passes of this build committed under profiles/
+            # (profiles/tools/profile_step.sh; PMC cannot be collected inside a timed run); valid at that configuration only
+            rec = pmc_k.get(pmc_names.get(name, ""))
+            if rec:
+                return rec["hbm_bytes"], (f"profiles/{PMC_TRAFFIC_FILE} (2 x FETCH_SIZE + WRITE_SIZE, median per launch of "
+                                          f"{pmc_names[name]})")
+            return None
+
+        if headline:
+            names = dict(prof)
+            if dominant and dominant in names and names[dominant][0]:
+                roof = roofline_object(dominant, names[dominant][0], names[dominant][1], B, traffic_of(dominant))
+                roof["selected_by"] = "longest average launch in the probe window (HIP events around every kernel)"
+            src = prof if "wgrad" in prof else probe
+            if "wgrad" in src and src["wgrad"][0]:
+                roof_wgrad = roofline_object("wgrad", src["wgrad"][0], src["wgrad"][1], B, traffic_of("wgrad"))
+                roof_wgrad["kernel"] = "wgrad2_kernel<bf16>" if args.precision == "bf16" else "wgrad2_kernel<f32>"
+                roof_wgrad["measured_in"] = "timed windows" if src is prof else "probe window (events around every kernel)"
+            if roof is None:
+                roof = roof_wgrad
+            if roof is not None:
+                roof.update({"step_dense_equiv_tflops": value * f_dense / 1e12,
+                             "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                             # what the step really issues on MFMA: encoder GEMM 2*D*H + the two weight-gradient
+                             # contractions 4*D*H per activation (the decode and dpre products are sparse, k rows each)
+                             "f_exec_per_activation": 6 * D_MODEL * HIDDEN,
+                             "step_mfma_exec_frac": value * 6 * D_MODEL * HIDDEN / 1e12 / BF16_DENSE_PEAK_TFLOPS})
         out = {
             "metric": f"activations/sec through SAE train step (d={D_MODEL}->{HIDDEN}, " + ("relu+l1)" if args.relu else f"k={TOPK})"),
             "value": value, "unit": "activations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,6 +308,8 @@ def main() -> None:
                        **({"grad_exchange": trainer.grad_exchange} if world > 1 else {})},
             **({"rehearsal": True} if rehearse else {}),
             "roofline": roof,
+            "roofline_wgrad2": roof_wgrad,
+            "probe_kernel_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in probe.items()},
             "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS,
             "final_loss": last.loss if last is not None else None,
         }

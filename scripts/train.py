@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
-"""Train TopK SAEs on cached Whisper activations with the MI355X train step.
+"""Train TopK SAEs on Whisper activations with the MI355X train step.
 
 Same command line as the reference's ``scripts/train.py`` (``--config --layer --no-wandb
---extract-only --device --seed``, :40-81).  What differs:
+--extract-only --device --seed``, :40-81) and the same flow (:296-329): extract the activations of the
+configured layers when their cache is missing (or ``--extract-only`` asks for it), then train one SAE per layer.
+What differs:
 
-* activations are loaded once into the on-device ring buffer and batches are drawn there;
-* the Whisper model is only needed for extraction, which is outside this build's scope
-  (``--extract-only`` and missing caches say so instead of downloading a model);
-* ``--synthetic N`` trains on N synthetic activation rows (no cache needed; benchmarks, smoke runs);
+* the Whisper model comes from a LOCAL directory (``--whisper-path``, loaded with ``local_files_only``) or is a
+  seeded random-init model of the configured geometry (``--whisper-random-init``: smoke runs and tests) - never a
+  hub name: this build downloads nothing.  ``run()`` also takes a model OBJECT;
+* the mel features come from a tensor file (``--mel``: ``torch.save``d ``[N, n_mels, frames]``) or are synthetic
+  (``--synthetic-mel N``); audio decoding and the LibriSpeech loader stay outside this build;
+* ``--stream-to-ring``: extraction pushes the layer-normed activations straight into the on-device ring the trainer
+  samples from (one kernel per hooked call) - no ``.cpu()``, no cache file, no reload;
+* cached activations are loaded once into the on-device ring buffer and batches are drawn there;
+* ``--synthetic N`` trains on N synthetic activation rows (no cache and no model needed; benchmarks, smoke runs);
 * under ``torchrun`` every rank trains data-parallel on its shard of the rows (RCCL all-reduce).
 """
 
@@ -26,7 +33,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "whisper-sae_amd"))
 
 from whisper_sae.config import ExperimentConfig  # noqa: E402
-from whisper_sae.data.feature_cache import ActivationRing, FeatureCache, RingLoader  # noqa: E402
+from whisper_sae.data.feature_cache import ActivationRing, FeatureCache, RingLoader, extract_and_cache_features  # noqa: E402
 from whisper_sae.distributed import rank_and_world  # noqa: E402
 from whisper_sae.sae.model import create_sae  # noqa: E402
 from whisper_sae.sae.training import SAETrainer  # noqa: E402
@@ -42,6 +49,15 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--synthetic", type=int, default=0, metavar="N", help="use N synthetic activation rows")
     ap.add_argument("--epochs", type=int, default=None, help="override training.epochs")
+    ap.add_argument("--whisper-path", type=str, default=None,
+                    help="local directory of a Whisper checkpoint (HF format); loaded with local_files_only")
+    ap.add_argument("--whisper-random-init", action="store_true",
+                    help="seeded random-init Whisper of the configured geometry instead of a checkpoint (smoke runs)")
+    ap.add_argument("--mel", type=str, default=None, help="torch.save'd mel features [N, n_mels, frames] to extract from")
+    ap.add_argument("--synthetic-mel", type=int, default=0, metavar="N", help="extract from N synthetic mel clips")
+    ap.add_argument("--mel-frames", type=int, default=3000, help="frames per synthetic clip (3000 = 30 s)")
+    ap.add_argument("--stream-to-ring", action="store_true",
+                    help="push extracted activations straight into the training ring (no cache files)")
     return ap.parse_args(argv)
 
 
@@ -60,20 +76,64 @@ def parse_layer(spec: str):
     return kind, int(num)
 
 
+def load_whisper(cfg: ExperimentConfig, args, device):
+    """The Whisper model to extract from, or None when the command line names none."""
+    if args.whisper_path:
+        from transformers import WhisperForConditionalGeneration
+        model = WhisperForConditionalGeneration.from_pretrained(args.whisper_path, local_files_only=True)
+    elif args.whisper_random_init:
+        from transformers import WhisperConfig, WhisperForConditionalGeneration
+        w = cfg.whisper
+        heads = max(1, w.hidden_dim // 64)
+        wc = WhisperConfig(d_model=w.hidden_dim, encoder_layers=w.num_encoder_layers, decoder_layers=w.num_decoder_layers,
+                           encoder_attention_heads=heads, decoder_attention_heads=heads, encoder_ffn_dim=4 * w.hidden_dim,
+                           decoder_ffn_dim=4 * w.hidden_dim, max_source_positions=args.mel_frames // 2)
+        torch.manual_seed(cfg.training.seed)
+        model = WhisperForConditionalGeneration(wc)
+    else:
+        return None
+    return model.to(device).eval()
+
+
+def mel_batches(cfg: ExperimentConfig, args, model, batch_size: int = 16):
+    """Batches of mel features ``[B, n_mels, frames]`` (reference scripts/train.py:300-307 uses batches of 16)."""
+    if args.mel:
+        mel = torch.load(args.mel, weights_only=True)
+        if mel.ndim != 3:
+            raise SystemExit(f"--mel: expected [N, n_mels, frames], got {tuple(mel.shape)}")
+    elif args.synthetic_mel:
+        g = torch.Generator().manual_seed(cfg.training.seed)
+        mel = torch.randn(args.synthetic_mel, model.config.num_mel_bins, args.mel_frames, generator=g)
+    else:
+        raise SystemExit("extraction needs mel features: --mel FILE or --synthetic-mel N (audio decoding is outside this build)")
+    return [mel[i:i + batch_size] for i in range(0, mel.shape[0], batch_size)]
+
+
+def extract(cfg: ExperimentConfig, model, cache: FeatureCache, layers, device, batches, rings=None) -> dict:
+    enc = [i for c, i in layers if c == "encoder"]
+    dec = [i for c, i in layers if c == "decoder"]
+    all_in_rings = bool(rings) and all(key in rings for key in layers)
+    return extract_and_cache_features(model, None, batches, None if all_in_rings else cache, enc, dec, device=device,
+                                      max_samples=cfg.data.max_samples, rings=rings)
+
+
 def train_layer(cfg: ExperimentConfig, component: str, layer_idx: int, cache: FeatureCache, device, synthetic: int,
-                epochs: int | None) -> None:
+                epochs: int | None, ring: ActivationRing | None = None) -> None:
     rank, world = rank_and_world()
     dtype = torch.bfloat16 if cfg.training.use_amp else torch.float32
-    if synthetic:
+    resample_rows = None
+    if ring is not None:  # filled by the extraction pass of this very run (--stream-to-ring)
+        dim = ring.dim
+        print(f"training from the ring the extraction filled: {len(ring):,} tokens, dim={dim}")
+    elif synthetic:
         dim = cfg.whisper.hidden_dim
         ring = ActivationRing(synthetic, dim, device=device, dtype=dtype)
         ring.fill_synthetic(synthetic, seed=cfg.training.seed + rank)
-        resample_rows = None
     else:
         if not cache.has_cache(component, layer_idx):
-            print(f"no cached activations for {component} layer {layer_idx} under {cache.cache_dir}; extraction "
-                  f"(Whisper forward hooks) is outside this build -- produce the cache with the reference's "
-                  f"--extract-only, or pass --synthetic N")
+            print(f"no cached activations for {component} layer {layer_idx} under {cache.cache_dir}: run with "
+                  f"--whisper-path DIR (or --whisper-random-init) and --mel FILE (or --synthetic-mel N) to extract them, "
+                  f"point data.cache_dir at a cache the reference's --extract-only wrote, or pass --synthetic N")
             return
         feats, meta = cache.load(component, layer_idx)
         dim = feats.shape[1]
@@ -107,16 +167,8 @@ def train_layer(cfg: ExperimentConfig, component: str, layer_idx: int, cache: Fe
         trainer.wandb_run.finish()
 
 
-def main(argv=None) -> None:
-    args = parse_args(argv)
-    cfg = ExperimentConfig.from_yaml(args.config) if args.config else ExperimentConfig()
-    if args.seed is not None:
-        cfg.training.seed = args.seed
-    if args.no_wandb:
-        cfg.wandb.enabled = False
-    if args.extract_only:
-        raise SystemExit("--extract-only (Whisper activation extraction) is outside this build's scope; run the "
-                         "reference's extraction and point data.cache_dir at its cache")
+def run(cfg: ExperimentConfig, args, whisper_model=None) -> None:
+    """Everything after argument parsing; ``whisper_model`` may be handed in as an object (tests, notebooks)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device(args.device) if args.device else torch.device("cuda", local)
@@ -133,11 +185,57 @@ def main(argv=None) -> None:
         layers = [parse_layer(args.layer)]
     else:
         layers = [("encoder", i) for i in cfg.encoder_layers] + [("decoder", i) for i in cfg.decoder_layers]
-    for component, idx in layers:
-        train_layer(cfg, component, idx, cache, device, args.synthetic, args.epochs)
+
+    # extraction (reference scripts/train.py:283-327): when a cache is missing, or on --extract-only
+    rings = {}
+    if not args.synthetic:
+        missing = [(c, i) for c, i in layers if not cache.has_cache(c, i)]
+        if missing or args.extract_only or args.stream_to_ring:
+            model = whisper_model if whisper_model is not None else load_whisper(cfg, args, device)
+            if model is None:
+                if args.extract_only:
+                    raise SystemExit("--extract-only needs a model: --whisper-path DIR or --whisper-random-init "
+                                     "(this build never downloads one by hub name)")
+            else:
+                model = model.to(device).eval()
+                batches = mel_batches(cfg, args, model)
+                if args.stream_to_ring and not args.extract_only:
+                    # one ring per layer, sized for what the extraction will push: whole batches while
+                    # num_samples < max_samples; an encoder layer yields frames / 2 rows per clip, a decoder layer one
+                    dtype = torch.bfloat16 if cfg.training.use_amp else torch.float32
+                    clips, taken = 0, 0
+                    for b in batches:
+                        if taken >= cfg.data.max_samples:
+                            break
+                        taken += b.shape[0]
+                        clips += b.shape[0]
+                    frames = batches[0].shape[-1]
+                    for c, i in layers:
+                        rows = clips * (frames // 2 if c == "encoder" else 1)
+                        rings[(c, i)] = ActivationRing(max(rows, 1), model.config.d_model, device=device, dtype=dtype)
+                todo = layers if (args.extract_only or rings) else missing
+                print(f"extracting {todo} with {type(model).__name__} (d_model {model.config.d_model})")
+                extract(cfg, model, cache, todo, device, batches, rings=rings or None)
+                del model
+                torch.cuda.empty_cache()
+    if args.extract_only:
+        print("extract-only mode, skipping training")
+    else:
+        for component, idx in layers:
+            train_layer(cfg, component, idx, cache, device, args.synthetic, args.epochs, ring=rings.get((component, idx)))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def main(argv=None, whisper_model=None) -> None:
+    args = parse_args(argv)
+    cfg = ExperimentConfig.from_yaml(args.config) if args.config else ExperimentConfig()
+    if args.seed is not None:
+        cfg.training.seed = args.seed
+    if args.no_wandb:
+        cfg.wandb.enabled = False
+    run(cfg, args, whisper_model=whisper_model)
 
 
 if __name__ == "__main__":

@@ -44,3 +44,20 @@ def golden_dir():
 @pytest.fixture(autouse=True)
 def set_seed():
     torch.manual_seed(42)
+
+
+@pytest.fixture(scope="session")
+def parity_note():
+    """``parity_note(key, measured, bound)``: append a measured parity gap to ``gpurun_out/parity_notes.jsonl`` (scratch;
+    the GPU run's copy is committed as ``profiles/rNN_parity_notes.jsonl``) so that the slack of every multi-step
+    tolerance is on record next to the bound the test enforces."""
+    import json
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    path = out / "parity_notes.jsonl"
+
+    def note(key: str, measured: float, bound: float) -> None:
+        with path.open("a") as fh:
+            fh.write(json.dumps({"key": key, "measured": float(measured), "bound": float(bound)}) + "\n")
+
+    return note

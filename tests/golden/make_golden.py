@@ -23,6 +23,8 @@ Golden sets (SURVEY.md row C list):
   G14 activation producer: extract_features_batch on a seeded random-init tiny Whisper (N2)
   G15 TopKCrossLayerCrosscoder: seeded init, forward, every gradient, clock, decoder helpers (N4 sibling)
   G16 CrossLayerCrosscoder (ReLU + decoder-norm-weighted L1): forward, every gradient, clock
+  G17 extraction driver: extract_and_cache_features on the seeded tiny Whisper -> cache tensors + metadata (N2)
+  G4b 20-step trajectory at cfg2 dimensions (384 -> 3072, k = 32): loss / lr / l0 scalars + sampled final parameters
 
 ``python tests/golden/make_golden.py g10 g11`` regenerates only the named sets.
 """
@@ -193,6 +195,47 @@ def g4_trajectory():
         b_pre=sd["b_pre"], last_activated=sd["feature_last_activated"], step_count=sd["step_count"],
         exp_avg_We=opt["state"][1]["exp_avg"].numpy(), exp_avg_sq_We=opt["state"][1]["exp_avg_sq"].numpy(),  # parameters() order: b_pre, enc.W, enc.b, dec.W, dec.b
     )
+
+
+def g4b_trajectory_cfg2():
+    """SURVEY.md row C, "G4 ... loss/lr scalars at cfg2 dims": 20 reference steps at 384 -> 3072, k = 32 on
+    bf16-representable inputs and initial weights (what both arithmetic modes of the build can be fed unchanged).  Stored:
+    loss / lr / l0 / dead ratio per step, the smallest k / k+1 margin met, and of the final state the per-tensor norms plus a
+    few hundred sampled entries (scalars at these dimensions, not the 19 MB of tensors)."""
+    D, H, K, B, STEPS = 384, 3072, 32, 512, 20
+    w = synth.sae_weights(D, H, seed=11, bf16=True, b_pre_scale=0.1)
+    xs = synth.activations(B * STEPS, D, seed=11, stream=4, bf16=True).reshape(STEPS, B, D)
+    m = TopKSAE(D, H, k=K)
+    load_weights(m, w)
+    cfg = TrainingConfig(batch_size=B, learning_rate=1e-3, weight_decay=0.0, epochs=1, warmup_steps=5,
+                         gradient_clip=1.0, use_amp=False, num_workers=0)
+    losses, lrs, l0s, dead, margins = [], [], [], [], []
+    with tempfile.TemporaryDirectory() as td:
+        tr = SAETrainer(m, cfg, device="cpu", run_dir=Path(td))
+        tr.setup_scheduler(STEPS)
+        for s in range(STEPS):
+            with torch.no_grad():
+                pre = m.encoder(torch.from_numpy(xs[s]) - m.b_pre).numpy()
+            margins.append(synth.topk_margin(pre, K).min())
+            lrs.append(tr.optimizer.param_groups[0]["lr"])
+            met = tr.train_step(torch.from_numpy(xs[s]))
+            losses.append(met.loss)
+            l0s.append(met.l0)
+            dead.append(met.dead_feature_ratio)
+    sd = sd_numpy(m)
+    out = {"dims": np.array([D, H, K, B, STEPS]), "losses": np.array(losses, dtype=np.float64),
+           "lrs": np.array(lrs, dtype=np.float64), "l0": np.array(l0s, dtype=np.float64),
+           "dead": np.array(dead, dtype=np.float64), "min_margin": np.float64(min(margins)),
+           "margins": np.array(margins, dtype=np.float64),
+           "step_count": sd["step_count"], "last_activated": sd["feature_last_activated"]}
+    for key, short in (("encoder.weight", "W_e"), ("encoder.bias", "b_e"), ("decoder.weight", "W_d"),
+                       ("decoder.bias", "b_d"), ("b_pre", "b_pre")):
+        a = sd[key]
+        out[f"norm_{short}"] = np.float64(np.linalg.norm(a.astype(np.float64)))
+        pos = sample_positions(a.shape, min(256, a.size), seed=100 + len(short))
+        out[f"pos_{short}"] = pos
+        out[f"val_{short}"] = a.reshape(-1)[pos]
+    np.savez_compressed(HERE / "g4b_trajectory_cfg2.npz", **out)
 
 
 def g5_lr():
@@ -534,7 +577,42 @@ def g16_crosscoder_relu():
     np.savez_compressed(HERE / "g16_crosscoder_relu.npz", **out)
 
 
-SETS = {"g16": g16_crosscoder_relu, "g15": g15_crosscoder, "g14": g14_hooks, "g13": g13_feature_topk, "g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
+def g17_extraction_driver():
+    """data/feature_cache.py:200-306: extract_and_cache_features on the seeded tiny Whisper - three mel batches of two
+    clips, max_samples = 5 (whole batches are taken while fewer than 5 samples are in: the count ends at 6), encoder layers
+    0 and 1 - into a FeatureCache.  Stored: every cached tensor and every field of its metadata sidecar.  (Decoder layers:
+    with the transformers build of this image a decoder layer returns a bare tensor, the reference's hook takes output[0] of it
+    (hooks.py:99-101) and its driver then raises ValueError in flatten_activations - recorded as ``decoder_raises``.)"""
+    import contextlib
+    import io
+    import transformers
+    from whisper_sae.config import DataConfig, WhisperConfig  # reference
+    from whisper_sae.data.feature_cache import FeatureCache, extract_and_cache_features  # reference
+    model = tiny_whisper(0)
+    mel = synth.normal((8, 80, 100), 17, 1).astype(np.float32)
+    batches = [torch.from_numpy(mel[i:i + 2]) for i in range(0, 8, 2)]
+    out = {"mel": mel, "transformers_version": np.array(transformers.__version__), "torch_version": np.array(torch.__version__)}
+    with tempfile.TemporaryDirectory() as td:
+        fc = FeatureCache(Path(td), WhisperConfig(), DataConfig(cache_dir=Path("cache")))
+        with contextlib.redirect_stdout(io.StringIO()):
+            extract_and_cache_features(model, None, batches, fc, [0, 1], [], device="cpu", max_samples=5)
+            try:
+                extract_and_cache_features(model, None, batches[:1], fc, [], [1], device="cpu", max_samples=2)
+                out["decoder_raises"] = np.array("")
+            except Exception as exc:  # noqa: BLE001
+                out["decoder_raises"] = np.array(type(exc).__name__)
+        files = sorted(p.name for p in Path(td).iterdir())
+        out["files"] = np.array(files)
+        for comp, layer in (("encoder", 0), ("encoder", 1)):
+            feats, meta = fc.load(comp, layer)
+            out[f"{comp}.{layer}"] = feats.numpy()
+            md = json.loads(meta.to_json()) if hasattr(meta, "to_json") else dict(meta.__dict__)
+            md["created_at"] = ""
+            out[f"meta.{comp}.{layer}"] = np.array(json.dumps(md, sort_keys=True, default=str))
+    np.savez_compressed(HERE / "g17_extraction.npz", **out)
+
+
+SETS = {"g17": g17_extraction_driver, "g16": g16_crosscoder_relu, "g15": g15_crosscoder, "g14": g14_hooks, "g13": g13_feature_topk, "g12": g12_transcoders, "g1": g1_g2_g3, "g4": g4_trajectory, "g4b": g4b_trajectory_cfg2, "g5": g5_lr, "g6": g6_dead, "g7": g7_resample, "g8": g8_relu,
         "g10": g10_seeded_init, "g11": g11_cache_interchange}
 
 if __name__ == "__main__":

@@ -102,6 +102,25 @@ class TestHostSide:
         with pytest.raises(ValueError):
             TopKTracker(num_features=8, k=65)
 
+    def test_prune_keeps_the_segment_being_recorded(self, monkeypatch):
+        # the bookkeeping of _record/_prune with the device merge stubbed out: after every update the newest segment is
+        # still there and ordinals bisect to the segment that produced them
+        t = TopKTracker(4, 2)
+        t._prune_at = 8
+        hv, ho, hc = t._host
+        t._vals = object()  # "device state exists": _sync_host is a no-op while _host_valid stays True
+        for u in range(100):
+            base = t._record(1, 1, [500 + u], None, None)
+            assert t._segments[-1].base == base and t._bases[-1] == base
+            f = u % 4  # pretend the merge put this update at the head of list f
+            ho[f, 1], ho[f, 0] = ho[f, 0], base
+            hc[f] = min(hc[f] + 1, 2)
+        assert len(t._segments) <= 17
+        for f in range(4):
+            for j in range(2):
+                seg = t._segments[__import__("bisect").bisect_right(t._bases, int(ho[f, j])) - 1]
+                assert seg.base == int(ho[f, j]) and seg.samples == [500 + int(ho[f, j])]
+
     def test_load_reads_the_reference_schema(self, tmp_path):
         # the JSON a reference TopKTracker.save writes (feature_viz.py:209-229)
         ex = [FeatureActivation(10, 0.7, 1, 0, 0.0, "b").to_dict(), FeatureActivation(10, 0.5, 0, 0, 0.0, "a").to_dict()]
@@ -158,6 +177,30 @@ class TestDeviceTracker:
         assert np.array_equal(hc, c) and t.total_activations == o.total_activations
         mask = np.arange(keep)[None, :] < c[:, None]
         assert np.array_equal(hv[mask], v[mask]) and np.array_equal(ho[mask], ords[mask])
+
+    def test_more_than_512_updates_prune_and_keep_the_join(self, device):
+        # _prune ran between the append and the merge of an update and dropped the segment just added;
+        # every list read after the 513th update then raised IndexError or joined the wrong sample
+        H, K, keep, per = 64, 4, 3, 2
+        o = FeatureTopK(H, keep)
+        t = TopKTracker(H, keep, device=device)
+        n_up = 1300
+        for u in range(n_up):
+            raw = synth.counter_u64(per * K, 91, u).reshape(per, K)
+            vals = ((raw % np.uint64(1000)).astype(np.float32) + 1.0 + u * 0.01)
+            idx = np.stack([np.argsort(synth.counter_u64(H, 92, u * per + r))[:K] for r in range(per)]).astype(np.int32)
+            o.update_compact(vals, idx)
+            t.update_compact(torch.from_numpy(vals).to(device), torch.from_numpy(idx).to(device),
+                             [1000 + u * per + r for r in range(per)])
+        assert len(t._segments) < n_up  # pruning did happen
+        v, ords, c = o.arrays()
+        for f in range(H):
+            ex = t.get_top_examples(f)
+            assert len(ex) == c[f]
+            for j, e in enumerate(ex):
+                assert np.float32(e.activation_value) == v[f, j]
+                assert e.sample_idx == 1000 + int(ords[f, j]) and e.position_idx == 0
+        assert len(t.get_all_top_examples()) == int((c > 0).sum())
 
     def test_dense_and_compact_agree_at_bench_size(self, device):
         # 16384 rows x k = 32 of 3072 features: the code the benchmark's encoder emits, one call; the same entries

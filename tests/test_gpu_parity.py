@@ -26,6 +26,11 @@ GOLDEN_ROOT = Path(__file__).resolve().parents[1]
 
 KEYS = ("encoder.weight", "encoder.bias", "decoder.weight", "decoder.bias", "b_pre")
 
+# multi-step / renormalised-tensor tolerances: measured on the MI355X (profiles/r03_parity_notes.jsonl) x 3
+G3_WD_ABS = 2e-6
+G4_LOSS_REL = 5e-5
+G4_STATE_REL = 2e-4
+
 
 def rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
@@ -192,7 +197,7 @@ class TestShapesAgainstOracle:
 
 
 class TestTrainStep:
-    def test_g3_one_step_fp32(self, g1, golden_dir, device, tmp_path):
+    def test_g3_one_step_fp32(self, g1, golden_dir, device, tmp_path, parity_note):
         from whisper_sae.config import TrainingConfig
         from whisper_sae.sae.training import SAETrainer, TrainingMetrics
         g3 = np.load(golden_dir / "g3_train_step_cfg2.npz")
@@ -216,8 +221,14 @@ class TestTrainStep:
         sd = {k: cpu(v) for k, v in m.state_dict().items()}
         for name, key in (("encoder.bias", "b_e"), ("decoder.bias", "b_d"), ("b_pre", "b_pre")):
             assert np.abs(sd[name] - g3[key]).max() < 2e-7, name
-        assert np.abs(sd["encoder.weight"].reshape(-1)[g3["pos_e"]] - g3["W_e_samples"]).max() < 2e-7
-        assert np.abs(sd["decoder.weight"].reshape(-1)[g3["pos_d"]] - g3["W_d_samples"]).max() < 2e-6
+        d_e = np.abs(sd["encoder.weight"].reshape(-1)[g3["pos_e"]] - g3["W_e_samples"]).max()
+        d_d = np.abs(sd["decoder.weight"].reshape(-1)[g3["pos_d"]] - g3["W_d_samples"]).max()
+        parity_note("g3_We_abs", d_e, 2e-7)
+        parity_note("g3_Wd_abs", d_d, G3_WD_ABS)
+        assert d_e < 2e-7
+        # W_d entries are O(0.1) after the renorm (W_e entries O(0.01)): one fp32 ulp there is 7.5e-9 and the renorm divides by
+        # a norm both sides sum in a different order; bound = measured x 3 (parity_notes.jsonl)
+        assert d_d < G3_WD_ABS
         cn = np.linalg.norm(sd["decoder.weight"].astype(np.float64), axis=0)
         assert abs(cn.min() - 1) < 1e-5 and abs(cn.max() - 1) < 1e-5  # ref test_training.py:314-326
         # tuple / list batch forms (ref test_training.py:120-148), same losses as the reference's steps 2, 3
@@ -227,7 +238,7 @@ class TestTrainStep:
         assert abs(met_l.loss - g3["losses_3steps"][2]) / g3["losses_3steps"][2] < 2e-5
         assert met_l.learning_rate == g3["lrs_3steps"][2]
 
-    def test_g4_trajectory_fp32(self, golden_dir, device, tmp_path):
+    def test_g4_trajectory_fp32(self, golden_dir, device, tmp_path, parity_note):
         from whisper_sae.config import TrainingConfig
         from whisper_sae.sae.training import SAETrainer
         g = np.load(golden_dir / "g4_trajectory_small.npz")
@@ -239,19 +250,58 @@ class TestTrainStep:
         tr.setup_scheduler(STEPS)
         xs = synth.activations(B * STEPS, D, seed=7, stream=2, bf16=False).reshape(STEPS, B, D)
         mets = [tr.train_step(torch.from_numpy(xs[s])) for s in range(STEPS)]
+        parity_note("g4_loss_rel_fp32", max(abs(met.loss - g["losses"][s]) / g["losses"][s] for s, met in enumerate(mets)), G4_LOSS_REL)
         for s, met in enumerate(mets):
-            assert abs(met.loss - g["losses"][s]) / g["losses"][s] < 5e-5, s
+            assert abs(met.loss - g["losses"][s]) / g["losses"][s] < G4_LOSS_REL, s
             assert met.dead_feature_ratio == pytest.approx(g["dead"][s], abs=1e-7), s
         sd = {k: cpu(v) for k, v in m.state_dict().items()}
-        assert rel(sd["encoder.weight"], g["W_e"]) < 2e-4
-        assert rel(sd["decoder.weight"], g["W_d"]) < 2e-4
-        assert rel(sd["b_pre"], g["b_pre"]) < 2e-4
+        parity_note("g4_state_rel_fp32", max(rel(sd["encoder.weight"], g["W_e"]), rel(sd["decoder.weight"], g["W_d"]),
+                                             rel(sd["b_pre"], g["b_pre"])), G4_STATE_REL)
+        assert rel(sd["encoder.weight"], g["W_e"]) < G4_STATE_REL
+        assert rel(sd["decoder.weight"], g["W_d"]) < G4_STATE_REL
+        assert rel(sd["b_pre"], g["b_pre"]) < G4_STATE_REL
         assert np.array_equal(m.feature_last_activated.cpu().numpy(), g["last_activated"])
         assert int(m.step_count.item()) == int(g["step_count"])
         osd = tr.optimizer.state_dict()
-        assert rel(cpu(osd["state"][1]["exp_avg"]), g["exp_avg_We"]) < 2e-4
-        assert rel(cpu(osd["state"][1]["exp_avg_sq"]), g["exp_avg_sq_We"]) < 2e-4
+        parity_note("g4_moments_rel_fp32", max(rel(cpu(osd["state"][1]["exp_avg"]), g["exp_avg_We"]),
+                                               rel(cpu(osd["state"][1]["exp_avg_sq"]), g["exp_avg_sq_We"])), G4_STATE_REL)
+        assert rel(cpu(osd["state"][1]["exp_avg"]), g["exp_avg_We"]) < G4_STATE_REL
+        assert rel(cpu(osd["state"][1]["exp_avg_sq"]), g["exp_avg_sq_We"]) < G4_STATE_REL
         assert float(osd["state"][1]["step"]) == STEPS
+
+    @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+    def test_g4b_trajectory_cfg2(self, golden_dir, device, tmp_path, precision, parity_note):
+        """The reference's 20 steps at 384 -> 3072, k = 32, B = 512 (G4b) against the product trainer in
+        both arithmetic modes.  The oracle's own gap to these numbers (tests/test_oracle_golden.py::TestTrajectoryG4b,
+        measured 2.0e-5 fp32 / 3.9e-4 amp) says what two fp32 implementations with different summation orders can
+        agree on over 20 Adam steps; the bounds here are measured x 3 and every measured value is written to
+        parity_notes.jsonl."""
+        from whisper_sae.config import TrainingConfig
+        from whisper_sae.sae.training import SAETrainer
+        g = np.load(golden_dir / "g4b_trajectory_cfg2.npz")
+        D, H, K, B, STEPS = (int(v) for v in g["dims"])
+        m, _ = build(D, H, K, 11, True, 0.1, 10_000, "cpu", None)
+        cfg = TrainingConfig(batch_size=B, learning_rate=1e-3, weight_decay=0.0, epochs=1, warmup_steps=5,
+                             gradient_clip=1.0, use_amp=(precision == "bf16"), num_workers=0)
+        tr = SAETrainer(m, cfg, device=device, run_dir=tmp_path)
+        tr.setup_scheduler(STEPS)
+        xs = synth.activations(B * STEPS, D, seed=11, stream=4, bf16=True).reshape(STEPS, B, D)
+        mets = [tr.train_step(torch.from_numpy(xs[s])) for s in range(STEPS)]
+        gap = max(abs(met.loss - g["losses"][s]) / g["losses"][s] for s, met in enumerate(mets))
+        for s, met in enumerate(mets):
+            assert met.l0 == g["l0"][s] and met.dead_feature_ratio == g["dead"][s], s
+            if s + 1 < STEPS:  # the metric carries the rate AFTER the scheduler step = the next step's rate
+                assert met.learning_rate == pytest.approx(g["lrs"][s + 1], rel=1e-9), s
+        sd = {k: cpu(v) for k, v in m.state_dict().items()}
+        drift = max(np.abs(sd[key].reshape(-1)[g[f"pos_{short}"]] - g[f"val_{short}"]).max() / np.abs(g[f"val_{short}"]).max()
+                    for key, short in (("encoder.weight", "W_e"), ("decoder.weight", "W_d"), ("encoder.bias", "b_e"),
+                                       ("decoder.bias", "b_d"), ("b_pre", "b_pre")))
+        loss_bound, drift_bound = (6e-5, 9e-4) if precision == "fp32" else (1.2e-3, 0.15)
+        parity_note(f"g4b_loss_gap_{precision}", gap, loss_bound)
+        parity_note(f"g4b_param_drift_{precision}", drift, drift_bound)
+        assert gap < loss_bound, gap
+        assert drift < drift_bound, drift
+        assert int(m.step_count.item()) == int(g["step_count"])
 
     def test_bf16_step_tracks_amp_oracle(self, device, tmp_path):
         from whisper_sae.config import TrainingConfig

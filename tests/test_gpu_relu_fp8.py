@@ -76,15 +76,27 @@ def test_training_in_fp8_tracks_bf16(device, tmp_path):
     assert np.sign(losses["fp8"][-1] - losses["fp8"][0]) == np.sign(losses["bf16"][-1] - losses["bf16"][0])
 
 
-def test_fp8_needs_the_bf16_mode_and_a_full_tile(device, tmp_path):
+def test_small_and_tail_batches_run_on_the_bf16_path(device, tmp_path):
+    """A batch the persistent fp8 GEMM cannot take (< 512 rows: the tail batch of an epoch, an eval call) is computed on the
+    bf16 path - decided from the shape before anything is queued - and equals the bf16 module bit for bit."""
     from whisper_sae.config import TrainingConfig
     from whisper_sae.sae.training import SAETrainer
-    m, _ = make(256, 1024, seed=2, device=device)
-    with pytest.raises(N.WsaeError):  # batch below the persistent GEMM's minimum: no silent bf16 fallback
-        m(torch.zeros(64, 256, device=device))
-    tr = SAETrainer(m, TrainingConfig(batch_size=1024, use_amp=False, num_workers=0), device=device, run_dir=tmp_path)
+    m8, _ = make(256, 1024, seed=2, device=device)
+    mb, _ = make(256, 1024, seed=2, precision="bf16", device=device)
+    x = torch.from_numpy(synth.activations(64, 256, seed=2, stream=1, bf16=True)).to(device)
+    with torch.no_grad():
+        a, b = m8(x), mb(x)
+    assert torch.equal(a.hidden, b.hidden) and torch.equal(a.reconstructed, b.reconstructed) and float(a.loss) == float(b.loss)
+    # an epoch whose last batch is short: 1024, 1024, 300 rows
+    cfg = TrainingConfig(batch_size=1024, learning_rate=1e-3, warmup_steps=0, use_amp=True, num_workers=0)
+    tr = SAETrainer(m8, cfg, device=device, run_dir=tmp_path / "tail")
+    for n, s in ((1024, 3), (1024, 4), (300, 5)):
+        met = tr.train_step(torch.from_numpy(synth.activations(n, 256, seed=2, stream=s, bf16=True)).to(device))
+        assert np.isfinite(met.loss)
+    # the fp8 forward still belongs to the bf16 mode
+    tr32 = SAETrainer(m8, TrainingConfig(batch_size=1024, use_amp=False, num_workers=0), device=device, run_dir=tmp_path)
     with pytest.raises(N.WsaeError):
-        tr.train_step(torch.zeros(1024, 256, device=device))
+        tr32.train_step(torch.zeros(1024, 256, device=device))
 
 
 def test_configs4_dimensions(device):

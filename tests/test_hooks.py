@@ -143,9 +143,16 @@ class TestIntoTheRing:
         model = tiny_whisper(0).to(device)
         mel = torch.from_numpy(g14["mel"]).to(device)
         ring = ActivationRing(4096, 64, device=device, dtype=torch.float32)
-        r = extract_features_batch(model, mel, [0, 1], [1], True, device, rings={("encoder", 1): ring})
+        r = extract_features_batch(model, mel, [0, 1], [1], True, device, rings={("encoder", 1): ring}, keep_on_device=True)
         torch.cuda.synchronize()
         assert 1 not in r["encoder"] and 0 in r["encoder"] and r["encoder"][0].is_cuda  # layer 1 went to the ring, layer 0 stayed on the GPU
+        r_host = extract_features_batch(model, mel, [0], [], True, device)  # default: the reference's .cpu() (hooks.py:92)
+        assert not r_host["encoder"][0].is_cuda and torch.equal(r_host["encoder"][0], r["encoder"][0].cpu())
+        ring.clear() if hasattr(ring, "clear") else None
+        ring2 = ActivationRing(4096, 64, device=device, dtype=torch.float32)
+        extract_features_batch(model, mel, [1], [], True, device, rings={("encoder", 1): ring2})
+        torch.cuda.synchronize()
+        ring = ring2
         want = torch.from_numpy(g14["ln.flat"]).to(device)  # the reference's layer-normed, flattened activations (CPU)
         assert len(ring) == want.shape[0]
         assert torch.allclose(ring.data[:len(ring)], want, rtol=2e-4, atol=2e-4)  # GPU vs CPU attention arithmetic

@@ -146,6 +146,51 @@ class TestTrajectoryG4:
         assert rel(st.adam_v["W_e"], g["exp_avg_sq_We"]) < 1e-4
 
 
+class TestTrajectoryG4b:
+    """the reference's 20-step loss / lr scalars at cfg2 dimensions (384 -> 3072, k = 32, B = 512),
+    bf16-representable inputs and initial weights.  Measured here (numpy oracle against the torch reference, both fp32 with
+    different summation orders): worst relative loss gap 2.0e-5, sampled final parameters within 2.9e-4 of the tensor's
+    largest entry - Adam's first updates are lr * m / sqrt(v) ~ lr * sign(g), so an entry whose gradient is within rounding
+    of zero moves by up to 2 lr in either direction; the one-step pins (G1 - G3) hold 1e-5 / 2e-7, a multi-step trajectory
+    cannot.  Bounds = measured x 3.  The "amp" mode (what the bf16 kernels mirror) is held to the SAME reference numbers:
+    its measured gap, 3.9e-4 in the loss, is the price of bf16 operands over 20 steps and is recorded, not hidden."""
+
+    @pytest.fixture(scope="class")
+    def run(self, golden_dir):
+        g = np.load(golden_dir / "g4b_trajectory_cfg2.npz")
+        D, H, K, B, STEPS = (int(v) for v in g["dims"])
+        w = synth.sae_weights(D, H, seed=11, bf16=True, b_pre_scale=0.1)
+        xs = synth.activations(B * STEPS, D, seed=11, stream=4, bf16=True).reshape(STEPS, B, D)
+        out = {}
+        for mode in ("fp32", "amp"):
+            st = O.SAEState.from_state_dict(w, k=K)
+            gaps = []
+            for s in range(STEPS):
+                lr = O.lr_at(s, 1e-3, 5, STEPS)
+                assert abs(lr - g["lrs"][s]) < 1e-9 * 1e-3, s
+                r = O.train_step(st, xs[s], lr, mode, max_norm=1.0, weight_decay=0.0)
+                gaps.append(abs(r["loss"] - g["losses"][s]) / g["losses"][s])
+                assert r["l0"] == g["l0"][s] and r["dead_feature_ratio"] == g["dead"][s], (mode, s)
+            out[mode] = (max(gaps), st)
+        return g, out
+
+    def test_fp32_mode_tracks_the_reference(self, run):
+        g, out = run
+        gap, st = out["fp32"]
+        assert gap < 6e-5, gap  # measured 2.0e-5
+        for short, arr in (("W_e", st.W_e), ("W_d", st.W_d), ("b_e", st.b_e), ("b_d", st.b_d), ("b_pre", st.b_pre)):
+            got = arr.reshape(-1)[g[f"pos_{short}"]]
+            assert np.abs(got - g[f"val_{short}"]).max() < 9e-4 * np.abs(g[f"val_{short}"]).max(), short  # measured <= 2.9e-4
+            assert abs(np.linalg.norm(arr.astype(np.float64)) - g[f"norm_{short}"]) < 6e-6 * g[f"norm_{short}"], short  # 1.8e-6
+        assert st.step_count == int(g["step_count"])
+
+    def test_amp_mode_gap_to_the_reference_is_bounded(self, run):
+        g, out = run
+        gap, st = out["amp"]
+        assert gap < 1.2e-3, gap  # measured 3.9e-4: bf16 operands, 20 steps
+        assert abs(np.linalg.norm(st.W_e.astype(np.float64)) - g["norm_W_e"]) < 5e-5 * g["norm_W_e"]  # measured 1.4e-5
+
+
 class TestLRScheduleG5:
     def test_all_cases(self, golden_dir):
         cases = json.loads((golden_dir / "g5_lr_schedule.json").read_text())

@@ -466,7 +466,10 @@ int forward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     const ReluWs ws = host_ws(ctx);
     // fp8 forward (BF16 mode + wsae_ctx_set_relu_fp8): the two forward GEMMs take e4m3 copies of their operands, one
     // dequantisation scale per row; everything else (hidden, residual, loss, the whole backward) is the bf16 path's
-    const bool fp8 = sizeof(T) == 2 && ctx->relu_fp8;
+    // Eligibility is decided from the shape BEFORE anything is queued (the conditions of wsae_internal_gemm256d_fp8 for
+    // both GEMMs): a tail batch of an epoch or a small eval batch under precision = "fp8" runs on the bf16 path instead of
+    // failing after its quantisation launches.
+    const bool fp8 = sizeof(T) == 2 && ctx->relu_fp8 && B >= 512 && D >= 128 && D % 256 == 0 && H % 256 == 0;
     int rc = fp8 ? wsae_internal_stage(ctx, params, x, x_dtype, rows, B, st)  // (the backward reads the staged xT)
                  : wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, nullptr, 0, st);  // pre = x W_e^T + b_e
     if (rc) return rc;

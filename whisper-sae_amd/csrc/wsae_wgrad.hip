@@ -189,6 +189,75 @@ bucket_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// bucket_sort_kernel: the counting sort of bucket_kernel's first block kind alone, for the row-major contraction (no
+// transposition blocks in the launch).  1024 threads per 64-row chunk, every entry (feature, value, dpre) fetched ONCE,
+// up front, into registers: the count pass and the scatter pass both run from there, so a block pays one global round trip
+// instead of two, with 16 waves per CU in flight instead of 4.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024)
+bucket_sort_kernel(const float* __restrict__ vals, const int32_t* __restrict__ idx, const float* __restrict__ dpre, int B,
+                   int K, int ntiles, int tw, uint32_t* __restrict__ ent_pos, T* __restrict__ ent_hid, T* __restrict__ ent_dpre,
+                   int32_t* __restrict__ ent_off) {
+    __shared__ int cnt[BUCKET_MAX_TILES];
+    __shared__ int cur[BUCKET_MAX_TILES];
+    constexpr int KT = Mfma<T>::KT;
+    constexpr int EB = 4;  // entries per thread: KT * K <= 64 * 64 = 4096
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x;
+    const int b0 = chunk * KT;
+    const int nent = min(KT, B - b0) * K;
+    const int64_t base = (int64_t)b0 * K;
+    int f[EB];
+    float v[EB], dp[EB];
+#pragma unroll
+    for (int j = 0; j < EB; ++j) {
+        const int e = min(tid + 1024 * j, nent - 1);
+        f[j] = idx[base + e];
+        v[j] = vals[base + e];
+        dp[j] = dpre[base + e];
+    }
+    for (int t = tid; t < ntiles; t += 1024) cnt[t] = 0;
+    __syncthreads();
+    int tl[EB];
+#pragma unroll
+    for (int j = 0; j < EB; ++j) {
+        tl[j] = f[j] / tw;
+        if (tid + 1024 * j < nent) atomicAdd(&cnt[tl[j]], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan over tiles by one wave
+        int carry = 0;
+        for (int t0 = 0; t0 < ntiles; t0 += 64) {
+            const int t = t0 + tid;
+            const int c = t < ntiles ? cnt[t] : 0;
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int n = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += n;
+            }
+            if (t < ntiles) {
+                cur[t] = carry + incl - c;
+                ent_off[(int64_t)chunk * (ntiles + 1) + t] = (int)base + carry + incl - c;
+            }
+            carry += __shfl(incl, 63, 64);
+        }
+        if (tid == 0) ent_off[(int64_t)chunk * (ntiles + 1) + ntiles] = (int)base + carry;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EB; ++j) {
+        const int e = tid + 1024 * j;
+        if (e >= nent) continue;
+        const int p = atomicAdd(&cur[tl[j]], 1);
+        ent_pos[base + p] = ((uint32_t)(f[j] - tl[j] * tw) << 16) | (uint32_t)(e / K);
+        ent_hid[base + p] = (T)(v[j] > 0.f ? v[j] : 0.f);
+        ent_dpre[base + p] = (T)dp[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad_kernel: one 128-feature x 128-column tile of dW_dT (which = 0) or dW_e (which = 1) over one
 // batch split.  Per KT-row chunk: zero the sparse slice A[buf], scatter the tile's bucketed entries
 // into it, stage the dense slab Bt[buf], MFMA.  A and Bt are double-buffered so that two barriers
@@ -338,12 +407,24 @@ wgrad_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid
 #define W2_THREADS (64 * W2_WAVES)
 #define W2_PIECES (W2_N / 8 / W2_WAVES)  // 1 KB LDS-DMA pieces per wave and chunk
 
-template <typename T>
+// RM (bf16 only): the dense operands are read ROW-MAJOR as they already lie in memory - g as the decode launch leaves it
+// (gb [B][D]), x as the batch's rows of the activation ring (through the step's row list) or the staged xb [B][D] - so
+// no launch has to write the K-contiguous transposes xT / gT (2 x 12.6 MB out and back in per step).  Image of a stage's
+// dense operand: [6 column blocks of 64][64 batch rows][128 bytes]; one LDS-DMA piece = 8 batch rows x 128 bytes of
+// one column block (a wave's six pieces are the six column blocks of the same 8 rows: one row pointer per lane and
+// chunk); the MFMA B fragments are taken with ds_read_b64_tr_b16 (cdna guide T10): per 16-lane group 4 batch rows x
+// 16 columns, delivered column-major = 4 consecutive k of one column per lane, two reads per fragment.  Chunk c of
+// row r sits at slot c ^ rm_swz(r): a 32-lane half reads 4 rows x 64 bytes, rows r and r + 2 share a bank half and land in
+// different 64-byte halves of it (bit 2 of the slot), so the transposed reads are conflict-free.
+__device__ __forceinline__ int rm_swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+template <typename T, bool RM>
 __global__ void __launch_bounds__(W2_THREADS)
 wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid, const T* __restrict__ ent_dpre,
               const int32_t* __restrict__ ent_off, const T* __restrict__ xT, const T* __restrict__ gT, int B, int ldT,
               int H, int D, int nsplit, int ntm, int ntn, float* __restrict__ out, int64_t slab_stride,
-              float* __restrict__ dbe_slab) {
+              float* __restrict__ dbe_slab, const int32_t* __restrict__ xrows, int which0) {
+    static_assert(!RM || sizeof(T) == 2, "the row-major operand path is the bf16 one (16-bit transposed LDS reads)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = SWZ_ROW_BYTES / (int)sizeof(T);
     constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
@@ -351,11 +432,11 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
     const int wm = wave >> 2, wn = wave & 3;
     const int split = blockIdx.x % nsplit;
     int tile = blockIdx.x / nsplit;
-    const int which = tile / (ntm * ntn);  // 0: dW_dT (hidden, g)   1: dW_e (dpre, x_c)
-    tile -= which * ntm * ntn;
+    const int which = which0 + tile / (ntm * ntn);  // 0: dW_dT (hidden, g)   1: dW_e (dpre, x_c)
+    tile -= (which - which0) * ntm * ntn;
     const int tm = tile / ntn, tn = tile % ntn;
     const int f0 = tm * W2_M, d0 = tn * W2_N;
-    const T* Bt = which == 0 ? gT : xT;
+    const T* Bt = which == 0 ? gT : xT;  // RM: [B][D] row-major (x: indexed through xrows when given)
     const T* sv = which == 0 ? ent_hid : ent_dpre;
     const bool do_dbe = (which == 1) && (tn == 0);
 
@@ -377,15 +458,34 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
     const int dma_r = lane >> 3, dma_s = lane & 7;
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     // dense slab of chunk ck into stage 0 / 1: half of this wave's pieces per call (j0 = 0 or W2_PIECES / 2)
+    // RM: source row of this lane's pieces for the chunk the next dma3 calls fetch (set by rm_row, a chunk ahead)
+    // (rm_row only LOADS the row-list entry; rm_use turns it into the pointer at the top of the next iteration, so the
+    // wait hipcc puts in front of the first use of a loaded value falls behind that iteration's dma_wait, not into the MFMA
+    // phase the load was issued from - the hardware counts the asm DMA pieces in the same in-order vmcnt)
+    const T* rm_src = Bt;
+    int rm_b = 0;
+    const int rm_c = (dma_s ^ rm_swz(wave * 8 + dma_r)) * EPC;  // source chunk of this lane's LDS slot
+    auto rm_row = [&](int ck) {
+        const int b = min(ck * KT + wave * 8 + dma_r, B - 1);  // rows past the batch repeat its last row (their A columns are zero)
+        rm_b = (which == 1 && xrows) ? xrows[b] : b;
+    };
+    auto rm_use = [&]() { rm_src = Bt + (int64_t)rm_b * D; };
     auto dma3 = [&](int ck, int stage, int j0) {
 #pragma unroll
         for (int j = j0; j < j0 + W2_PIECES / 2; ++j) {
-            const int piece = wave + W2_WAVES * j;
-            const int row = piece * 8 + dma_r;
-            const int c = dma_s ^ ((row >> 1) & 7);
-            const int d = min(d0 + row, D - 1);  // columns past D repeat column D-1: never stored
-            const T* src = Bt + (int64_t)d * ldT + (int64_t)ck * KT + c * EPC;
-            glds16(src, smem_lds + stage * W2_STAGE + W2_A_BYTES + piece * 1024);
+            if constexpr (RM) {
+                // piece j of this wave: column block j (64 columns) of batch rows 8 wave .. 8 wave + 7
+                static_assert(!RM || (W2_PIECES == W2_N / 64 && W2_WAVES * 8 == 64), "one wave = 8 batch rows of every column block");
+                const int dcol = min(d0 + j * 64 + rm_c, D - EPC);  // column blocks past D repeat the last chunk: never stored
+                glds16(rm_src + dcol, smem_lds + stage * W2_STAGE + W2_A_BYTES + j * 8192 + wave * 1024);
+            } else {
+                const int piece = wave + W2_WAVES * j;
+                const int row = piece * 8 + dma_r;
+                const int c = dma_s ^ ((row >> 1) & 7);
+                const int d = min(d0 + row, D - 1);  // columns past D repeat column D-1: never stored
+                const T* src = Bt + (int64_t)d * ldT + (int64_t)ck * KT + c * EPC;
+                glds16(src, smem_lds + stage * W2_STAGE + W2_A_BYTES + piece * 1024);
+            }
         }
     };
     auto put = [&](char* As, uint32_t p, T v) {
@@ -427,8 +527,13 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
     if (c_begin < c_end) {
         offsets(c_begin);
         entries(c_begin);
+        if constexpr (RM) {
+            rm_row(c_begin);
+            rm_use();
+        }
         dma3(c_begin, 0, 0);
         dma3(c_begin, 0, W2_PIECES / 2);
+        if constexpr (RM) rm_row(min(c_begin + 1, c_end - 1));
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -445,9 +550,13 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
         char* nxt = smem + (buf ^ 1) * W2_STAGE;
         const bool more = ck + 1 < c_end;
         entries(min(ck + 1, c_end - 1));  // (the last iteration re-reads its own chunk: keeps p_* = this chunk)
+        if constexpr (RM) rm_use();       // row pointer of chunk ck + 1 (its list entry was requested a chunk ago)
         // (one call site: two copies of the MFMA phase made hipcc double the accumulators and spill)
-        Mfma96<T, W2_MI>::slab(cur, cur + W2_A_BYTES, wm * 32 * W2_MI, wn * 96, lane, acc, [&](int kk) {
+        Mfma96<T, W2_MI>::template slab<RM>(cur, cur + W2_A_BYTES, wm * 32 * W2_MI, wn * 96, lane, acc, [&](int kk) {
             if (more && kk < 2) dma3(ck + 1, buf ^ 1, kk * (W2_PIECES / 2));  // >= half a phase to land
+            if constexpr (RM) {
+                if (kk == 2) rm_row(min(ck + 2, c_end - 1));  // the row list entry of the chunk after next (an L2 hit by then)
+            }
         });
         if (do_dbe) {
             Mfma96<T, W2_MI>::rowsum16(cur, wave * 16, lane, rs0);
@@ -755,11 +864,19 @@ static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const
                          int64_t slab_stride, const void* x, const int32_t* rows) {
     constexpr int KT = Mfma<T>::KT;
     const int nchunks = ceil_div(B, KT);
+    // Row-major dense operands (wgrad2_kernel<bf16, RM>): g as the MFMA decode launch left it (gb), x as the staged batch
+    // xb or - when the encoder GEMM gathered its rows itself - the caller's bf16 rows through the row list.  Then the
+    // bucket launch is the counting sort alone: no g -> gT / x -> xT blocks.
+    const bool rm = sizeof(T) == 2 && nt == 0 && ctx->g_is_bf16 && ctx->D % 8 == 0;
     WSAE_PROF_BEGIN(ctx, WSAE_K_BUCKET, st);
-    // + the transposition of g (left row-major by the decode launch) as a second kind of block in the same launch
+    // otherwise: + the transposition of g (left row-major by the decode launch) as a second kind of block in the same launch
     // ... and, when no staging launch left xT (the encoder GEMM gathered the batch rows itself), of x as a third kind
-    const int ntr = (ldT / 64) * ceil_div(ctx->D, 64);
+    const int ntr = rm ? 0 : (ldT / 64) * ceil_div(ctx->D, 64);
     const int nxt = ctx->xT_valid ? 0 : ntr;
+    if (rm && KT * ctx->K <= 4096)
+        bucket_sort_kernel<T><<<nchunks, 1024, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, W2_M, ctx->ent_pos, (T*)ctx->ent_hid,
+                                                        (T*)ctx->ent_dpre, ctx->ent_off);
+    else
     bucket_kernel<T><<<nchunks + ntr + nxt, 256, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, nt == 0 ? W2_M : TILE_M, ctx->ent_pos,
                                                           (T*)ctx->ent_hid, (T*)ctx->ent_dpre, ctx->ent_off, nchunks, ctx->g,
                                                           ctx->g_is_bf16 ? ctx->gb : nullptr, (T*)ctx->gT, ctx->D, ldT,
@@ -768,7 +885,20 @@ static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD, st);
 #define WG_ARGS ctx->ent_pos, (const T*)ctx->ent_hid, (const T*)ctx->ent_dpre, ctx->ent_off, (const T*)ctx->xT, \
                 (const T*)ctx->gT, B, ldT, ctx->H, ctx->D, nsplit, ntm, ntn, out, slab_stride, ctx->dbe_slab
-    if (nt == 0) wgrad2_kernel<T><<<grid, W2_THREADS, 2 * W2_STAGE, st>>>(WG_ARGS);
+    if (nt == 0) {
+        if constexpr (sizeof(T) == 2) {
+            if (rm) {
+                const T* xsrc = ctx->xT_valid ? (const T*)ctx->xb : (const T*)x;
+                wgrad2_kernel<T, true><<<grid, W2_THREADS, 2 * W2_STAGE, st>>>(
+                    ctx->ent_pos, (const T*)ctx->ent_hid, (const T*)ctx->ent_dpre, ctx->ent_off, xsrc, (const T*)ctx->gb, B, ldT,
+                    ctx->H, ctx->D, nsplit, ntm, ntn, out, slab_stride, ctx->dbe_slab, ctx->xT_valid ? nullptr : rows, 0);
+            } else {
+                wgrad2_kernel<T, false><<<grid, W2_THREADS, 2 * W2_STAGE, st>>>(WG_ARGS, nullptr, 0);
+            }
+        } else {
+            wgrad2_kernel<T, false><<<grid, W2_THREADS, 2 * W2_STAGE, st>>>(WG_ARGS, nullptr, 0);
+        }
+    }
     else if (nt == 3) wgrad_kernel<T, 3><<<grid, 768, 2 * 4 * TILE_LDS_BYTES, st>>>(WG_ARGS);
     else if (nt == 2) wgrad_kernel<T, 2><<<grid, 512, 2 * 3 * TILE_LDS_BYTES, st>>>(WG_ARGS);
     else wgrad_kernel<T, 1><<<grid, 256, 2 * 2 * TILE_LDS_BYTES, st>>>(WG_ARGS);

@@ -86,6 +86,7 @@ class TopKTracker:
         self.samples_processed = 0
         self._next_ord = 0
         self._segments: list[_Segment] = []
+        self._prune_at = 512  # segments kept before the host records are pruned (doubles while most stay live)
         self._bases: list[int] = []
         # device state (created by the first update) and its host copy
         self._vals: Optional[Tensor] = None
@@ -143,6 +144,14 @@ class TopKTracker:
         samples = [int(s) for s in sample_indices]
         if len(samples) * seq_len != rows:
             raise ValueError(f"TopKTracker.update: {len(samples)} sample indices for {rows // max(seq_len, 1)} samples")
+        # prune BEFORE the new update is recorded: every earlier update has been merged into the device lists by then
+        # (pruning after the append dropped the segment just added, whose ordinals no list holds yet).  The threshold
+        # doubles whenever a prune leaves more than half of it alive, so a tracker whose segments all stay live does not
+        # synchronise the host on every update.
+        if len(self._segments) >= self._prune_at:
+            self._prune()
+            while len(self._segments) * 2 > self._prune_at:
+                self._prune_at *= 2
         base = self._next_ord
         self._segments.append(_Segment(base, rows, seq_len, samples, None,
                                        list(transcriptions) if transcriptions else None,
@@ -150,8 +159,6 @@ class TopKTracker:
         self._bases.append(base)
         self._next_ord += rows
         self.samples_processed += len(samples)
-        if len(self._segments) > 512:
-            self._prune()
         return base
 
     def _launch(self, vals: Tensor, idx: Optional[Tensor], rows: int, width: int, base: int) -> None:

@@ -9,7 +9,10 @@ the encode / decode kernels gather the rows from the ring themselves.
 The on-disk cache format is the reference's (so ``--extract-only`` caches are interchangeable):
 ``<cache>/<model_short>_<component>_layer<N>.pt`` = ``torch.save(float32 [num_tokens, hidden_dim])``
 plus ``..._meta.json`` with the ``CacheMetadata`` fields (feature_cache.py:23-57, :87-167).
-The extraction half (HF Whisper + audio) is out of scope of this build.
+
+``extract_and_cache_features`` (reference feature_cache.py:200-306) drives a Whisper model over batches of mel features
+and leaves the tapped layers' activations in the reference's cache files and / or directly in ``ActivationRing`` objects
+(row N2: producer -> ring -> trainer with no host round trip).  Audio IO and model download stay outside this build.
 """
 
 from __future__ import annotations
@@ -267,4 +270,87 @@ class FeatureCache:
         return RingLoader(ring, batch_size, shuffle=shuffle, seed=seed, rank=rank, world_size=world_size)
 
 
-__all__ = ["ActivationRing", "CacheMetadata", "FeatureCache", "RingBatch", "RingLoader", "require_device_tensor"]
+def extract_and_cache_features(whisper_model, processor, audio_dataloader, cache: Optional[FeatureCache], encoder_layers: list,
+                               decoder_layers: list, device="cpu", max_samples: Optional[int] = None,
+                               rings: Optional[dict] = None, show_progress: bool = True) -> dict:
+    """Run ``whisper_model`` over ``audio_dataloader`` and keep the tapped layers' activations (reference
+    feature_cache.py:200-306; same positional arguments - ``processor`` is accepted and, as in the reference, unused).
+
+    Every batch (a tensor of mel features ``[B, n_mels, frames]``, or a tuple / list whose first item is one) goes
+    through the encoder and, when decoder layers are tapped, one decoder step from the start token; the final LayerNorm
+    is applied to each tapped output (``apply_layer_norm=True`` as the reference hard-codes).  Batches are taken while
+    ``num_samples < max_samples`` - whole batches, so the count can overshoot exactly as the reference's does.
+
+    Where the activations go:
+
+    * layers named in ``rings`` (``{("encoder" | "decoder", layer): ActivationRing}``; not in the reference): LayerNorm +
+      push into the ring in one kernel per hooked call, nothing cached, nothing written;
+    * every other layer: flattened ``[tokens, D]`` chunks are collected on the host and written with ``cache.save`` - the
+      reference's ``.pt`` + ``_meta.json`` pair (``cache`` may be ``None`` only when every layer has a ring).
+
+    Returns ``{"num_samples": n, "tokens": {(component, layer): rows}}``.
+    """
+    from ..sae.hooks import WhisperActivationExtractor, flatten_activations, run_whisper_taps
+
+    del processor  # (the reference's signature; its body never reads it either)
+    rings = dict(rings or {})
+    wanted = [("encoder", i) for i in encoder_layers] + [("decoder", i) for i in decoder_layers]
+    unknown = [key for key in rings if key not in wanted]
+    if unknown:
+        raise ValueError(f"rings given for layers that are not extracted: {unknown}")
+    to_disk = [key for key in wanted if key not in rings]
+    if to_disk and cache is None:
+        raise ValueError(f"no FeatureCache for the layers without a ring: {to_disk}")
+    whisper_model = whisper_model.to(device)
+    whisper_model.eval()
+    extractor = WhisperActivationExtractor(model=whisper_model, encoder_layers=encoder_layers, decoder_layers=decoder_layers,
+                                           apply_layer_norm=True)
+    for (component, layer), ring in rings.items():
+        extractor.attach_ring(component, layer, ring)
+    chunks: dict = {key: [] for key in to_disk}
+    before = {key: len(ring) for key, ring in rings.items()}
+    num_samples = 0
+    limit = max_samples if max_samples else float("inf")
+
+    progress = task = None
+    if show_progress:
+        from rich.progress import BarColumn, Progress, SpinnerColumn, TaskProgressColumn, TextColumn
+        progress = Progress(SpinnerColumn(), TextColumn("[progress.description]{task.description}"), BarColumn(),
+                            TaskProgressColumn())
+        progress.start()
+        task = progress.add_task("[cyan]Extracting features...", total=max_samples if max_samples else None)
+    try:
+        with torch.no_grad(), extractor:
+            for batch in audio_dataloader:
+                if num_samples >= limit:
+                    break
+                if isinstance(batch, (list, tuple)):
+                    batch = batch[0]
+                batch_size = run_whisper_taps(whisper_model, extractor, batch, device)
+                for component, layer in to_disk:
+                    held = getattr(extractor.cache, component).get(layer)
+                    if held:  # this batch's capture (the hook appended exactly one tensor)
+                        chunks[(component, layer)].append(flatten_activations(held[-1], component))
+                extractor.clear_cache()  # the chunks are kept flattened; the reference's cache grows without bound
+                num_samples += batch_size
+                if progress is not None:
+                    progress.update(task, completed=min(num_samples, limit))
+    finally:
+        if progress is not None:
+            progress.stop()
+
+    tokens: dict = {}
+    for component, layer in to_disk:
+        if chunks[(component, layer)]:
+            features = torch.cat(chunks[(component, layer)], dim=0)
+            cache.save(features, component, layer, num_samples)
+            tokens[(component, layer)] = int(features.shape[0])
+            print(f"Cached {component} layer {layer}: {features.shape}")
+    for key, ring in rings.items():
+        tokens[key] = int(extractor.rows_delivered.get(key, 0))
+        print(f"Ring {key[0]} layer {key[1]}: {tokens[key]} rows pushed, {len(ring)} resident (was {before[key]})")
+    return {"num_samples": num_samples, "tokens": tokens}
+
+
+__all__ = ["ActivationRing", "CacheMetadata", "FeatureCache", "RingBatch", "RingLoader", "extract_and_cache_features",
+           "require_device_tensor"]
