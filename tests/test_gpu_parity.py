@@ -26,10 +26,13 @@ GOLDEN_ROOT = Path(__file__).resolve().parents[1]
 
 KEYS = ("encoder.weight", "encoder.bias", "decoder.weight", "decoder.bias", "b_pre")
 
-# multi-step / renormalised-tensor tolerances: measured on the MI355X (profiles/r03_parity_notes.jsonl) x 3
-G3_WD_ABS = 2e-6
-G4_LOSS_REL = 5e-5
-G4_STATE_REL = 2e-4
+# multi-step tolerances = measured on the MI355X x 3 (profiles/r03_parity_notes.jsonl holds the measured values: the fp32
+# mode's exact-fp32 MFMA is a k-ordered fmaf chain and tracks torch's CPU trajectory to ~1e-7 over 20 steps, two decades
+# inside north_star's 1e-5; round 2 carried 5e-5 / 2e-4 / 2e-6 here without saying how much of that was slack)
+G3_WD_ABS = 2e-7      # measured 5.2e-8 (the same bound as every other tensor of the one-step pin)
+G4_LOSS_REL = 7e-7    # measured 2.2e-7
+G4_STATE_REL = 2.5e-6  # measured 7.8e-7 (parameters)
+G4_MOMENT_REL = 4e-5  # measured 1.3e-5 (exp_avg_sq of entries whose gradient is near zero)
 
 
 def rel(a, b):
@@ -264,9 +267,9 @@ class TestTrainStep:
         assert int(m.step_count.item()) == int(g["step_count"])
         osd = tr.optimizer.state_dict()
         parity_note("g4_moments_rel_fp32", max(rel(cpu(osd["state"][1]["exp_avg"]), g["exp_avg_We"]),
-                                               rel(cpu(osd["state"][1]["exp_avg_sq"]), g["exp_avg_sq_We"])), G4_STATE_REL)
-        assert rel(cpu(osd["state"][1]["exp_avg"]), g["exp_avg_We"]) < G4_STATE_REL
-        assert rel(cpu(osd["state"][1]["exp_avg_sq"]), g["exp_avg_sq_We"]) < G4_STATE_REL
+                                               rel(cpu(osd["state"][1]["exp_avg_sq"]), g["exp_avg_sq_We"])), G4_MOMENT_REL)
+        assert rel(cpu(osd["state"][1]["exp_avg"]), g["exp_avg_We"]) < G4_MOMENT_REL
+        assert rel(cpu(osd["state"][1]["exp_avg_sq"]), g["exp_avg_sq_We"]) < G4_MOMENT_REL
         assert float(osd["state"][1]["step"]) == STEPS
 
     @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -296,7 +299,9 @@ class TestTrainStep:
         drift = max(np.abs(sd[key].reshape(-1)[g[f"pos_{short}"]] - g[f"val_{short}"]).max() / np.abs(g[f"val_{short}"]).max()
                     for key, short in (("encoder.weight", "W_e"), ("decoder.weight", "W_d"), ("encoder.bias", "b_e"),
                                        ("decoder.bias", "b_d"), ("b_pre", "b_pre")))
-        loss_bound, drift_bound = (6e-5, 9e-4) if precision == "fp32" else (1.2e-3, 0.15)
+        # measured on the MI355X: fp32 1.07e-7 / 3.1e-7 (the numpy oracle, with its own summation order, is 2.0e-5 / 2.9e-4
+        # away from the same reference numbers); bf16 2.8e-4 / 0.045 - the trajectory gap bf16 operands cost over 20 steps
+        loss_bound, drift_bound = (4e-7, 1e-6) if precision == "fp32" else (9e-4, 0.15)
         parity_note(f"g4b_loss_gap_{precision}", gap, loss_bound)
         parity_note(f"g4b_param_drift_{precision}", drift, drift_bound)
         assert gap < loss_bound, gap

@@ -15,6 +15,8 @@ import torch
 
 from whisper_sae.sae.hooks import ActivationCache, WhisperActivationExtractor, extract_features_batch, flatten_activations
 
+ROOT = __import__("pathlib").Path(__file__).resolve().parents[1]
+
 
 def tiny_whisper(seed: int = 0):
     from transformers import WhisperConfig, WhisperForConditionalGeneration
@@ -107,6 +109,64 @@ class TestReferenceBehaviour:
         assert f.shape == (6, 4) and torch.equal(f[4], t[1, 1])
 
 
+@pytest.fixture(scope="module")
+def g17(golden_dir):
+    return np.load(golden_dir / "g17_extraction.npz")
+
+
+class TestExtractionDriver:
+    """``extract_and_cache_features`` (reference data/feature_cache.py:200-306) against golden set G17: what the
+    reference's driver wrote for the seeded tiny Whisper - cache tensors and every field of the metadata sidecars."""
+
+    def _batches(self, g17):
+        mel = g17["mel"]
+        return [torch.from_numpy(mel[i:i + 2]) for i in range(0, mel.shape[0], 2)]
+
+    def test_cache_files_match_g17(self, g17, tmp_path, capsys):
+        import json
+        from whisper_sae.config import DataConfig, WhisperConfig
+        from whisper_sae.data.feature_cache import FeatureCache, extract_and_cache_features
+        if not versions_match(g17):
+            pytest.skip("G17 was generated with another transformers / torch build")
+        fc = FeatureCache(tmp_path, WhisperConfig(), DataConfig(cache_dir="cache"))
+        r = extract_and_cache_features(tiny_whisper(0), None, self._batches(g17), fc, [0, 1], [], device="cpu", max_samples=5,
+                                       show_progress=False)
+        assert r["num_samples"] == 6  # whole batches while fewer than max_samples are in: 2 + 2 + 2 (feature_cache.py:256-258)
+        assert sorted(p.name for p in tmp_path.iterdir()) == list(g17["files"])
+        for layer in (0, 1):
+            feats, meta = fc.load("encoder", layer)
+            assert np.array_equal(feats.numpy(), g17[f"encoder.{layer}"])  # same torch ops on the same machine arithmetic
+            want = json.loads(str(g17[f"meta.encoder.{layer}"]))
+            got = json.loads(meta.to_json())
+            got["created_at"] = ""
+            assert got == want
+            assert r["tokens"][("encoder", layer)] == want["num_tokens"]
+        assert "Cached encoder layer 0" in capsys.readouterr().out
+
+    def test_tuple_batches_and_argument_checks(self, g17, tmp_path):
+        from whisper_sae.config import DataConfig, WhisperConfig
+        from whisper_sae.data.feature_cache import FeatureCache, extract_and_cache_features
+        fc = FeatureCache(tmp_path, WhisperConfig(), DataConfig(cache_dir="cache"))
+        batches = [(b, "ignored") for b in self._batches(g17)[:1]]  # (features, ...) tuples as a DataLoader yields them
+        r = extract_and_cache_features(tiny_whisper(0), None, batches, fc, [1], [], device="cpu", show_progress=False)
+        assert r["num_samples"] == 2 and fc.has_cache("encoder", 1) and not fc.has_cache("encoder", 0)
+        with pytest.raises(ValueError):  # a ring for a layer that is not extracted
+            extract_and_cache_features(tiny_whisper(0), None, batches, fc, [1], [], rings={("encoder", 0): object()}, show_progress=False)
+        with pytest.raises(ValueError):  # no cache and no ring for a layer
+            extract_and_cache_features(tiny_whisper(0), None, batches, None, [1], [], show_progress=False)
+
+    def test_decoder_layers_fail_like_the_reference_on_this_transformers(self, g17, tmp_path):
+        # G17 records that the reference's driver raises ValueError for decoder layers with this transformers build (its hook
+        # takes output[0] of a bare tensor, hooks.py:99-101, and flatten_activations then meets a 2-D tensor): same here
+        from whisper_sae.config import DataConfig, WhisperConfig
+        from whisper_sae.data.feature_cache import FeatureCache, extract_and_cache_features
+        if not versions_match(g17) or str(g17["decoder_raises"]) != "ValueError":
+            pytest.skip("recorded for another transformers build")
+        fc = FeatureCache(tmp_path, WhisperConfig(), DataConfig(cache_dir="cache"))
+        with pytest.raises(ValueError):
+            extract_and_cache_features(tiny_whisper(0), None, self._batches(g17)[:1], fc, [], [1], device="cpu", show_progress=False)
+
+
 @pytest.mark.gpu
 class TestIntoTheRing:
     def test_layernorm_push_kernel(self, device):
@@ -165,3 +225,68 @@ class TestIntoTheRing:
         tr = SAETrainer(sae, TrainingConfig(batch_size=64, use_amp=False, num_workers=0), device=device)
         m = tr.train_step(next(iter(RingLoader(ring, 64, shuffle=True, seed=1))))
         assert np.isfinite(m.loss) and m.l0 == 8
+
+    def test_producer_ring_trainer_in_one_pass(self, g17, device, tmp_path):
+        """hooks -> ring -> 50 train steps: the driver pushes the layer-normed encoder activations of
+        the seeded tiny Whisper straight into ActivationRing objects, nothing is written, and an SAE trained on the ring's
+        rows lowers its loss."""
+        from whisper_sae.config import TrainingConfig
+        from whisper_sae.data import ActivationRing, RingLoader, extract_and_cache_features
+        from whisper_sae.sae.model import TopKSAE
+        from whisper_sae.sae.training import SAETrainer
+        model = tiny_whisper(0).to(device)
+        mel = torch.from_numpy(g17["mel"])
+        batches = [mel[i:i + 2] for i in range(0, 8, 2)]
+        rings = {("encoder", 0): ActivationRing(400, 64, device=device, dtype=torch.float32),
+                 ("encoder", 1): ActivationRing(400, 64, device=device, dtype=torch.float32)}
+        r = extract_and_cache_features(model, None, batches, None, [0, 1], [], device=device, rings=rings, show_progress=False)
+        torch.cuda.synchronize()
+        assert r["num_samples"] == 8 and r["tokens"] == {("encoder", 0): 400, ("encoder", 1): 400}
+        assert not any(tmp_path.iterdir())
+        want = torch.from_numpy(g17["encoder.1"]).to(device)  # the reference's first 6 clips (CPU arithmetic)
+        assert torch.allclose(rings[("encoder", 1)].data[:300], want, rtol=2e-4, atol=2e-4)
+        sae = TopKSAE(64, 512, k=8)
+        tr = SAETrainer(sae, TrainingConfig(batch_size=100, learning_rate=3e-3, warmup_steps=0, use_amp=False, num_workers=0),
+                        device=device, run_dir=tmp_path / "run")
+        loader = RingLoader(rings[("encoder", 1)], 100, shuffle=True, seed=3)
+        losses = []
+        while len(losses) < 50:
+            for b in loader:
+                losses.append(tr.train_step(b).loss)
+        assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+
+    def test_cli_extract_only_then_train_and_stream_to_ring(self, device, tmp_path):
+        """scripts/train.py: --extract-only writes the reference's cache files from a model OBJECT; a second run trains from
+        them; --stream-to-ring extracts and trains in one process without cache files (reference scripts/train.py:283-329)."""
+        import importlib.util
+        import yaml
+        spec = importlib.util.spec_from_file_location("wsae_train_cli", ROOT / "scripts" / "train.py")
+        cli = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(cli)
+        cfg = {"whisper": {"model_name": "local/tiny-random", "hidden_dim": 64, "num_encoder_layers": 2, "num_decoder_layers": 2},
+               "sae": {"expansion_factor": 4, "k": 8, "dead_feature_resample": False},
+               "training": {"batch_size": 64, "epochs": 2, "use_amp": False, "num_workers": 0, "warmup_steps": 0, "checkpoint_every": 1},
+               "data": {"cache_dir": str(tmp_path / "cache"), "max_samples": 6}, "wandb": {"enabled": False},
+               "encoder_layers": [1], "decoder_layers": [], "output_dir": str(tmp_path / "out"), "experiment_name": "n2"}
+        (tmp_path / "cfg.yaml").write_text(yaml.safe_dump(cfg))
+        mel = torch.randn(6, 80, 100, generator=torch.Generator().manual_seed(5))
+        torch.save(mel, tmp_path / "mel.pt")
+        base = ["--config", str(tmp_path / "cfg.yaml"), "--no-wandb", "--device", str(device), "--mel", str(tmp_path / "mel.pt")]
+        cli.main(base + ["--extract-only"], whisper_model=tiny_whisper(0))
+        feats = tmp_path / "cache" / "features" / "tiny-random_encoder_layer1.pt"
+        assert feats.exists() and (tmp_path / "cache" / "features" / "tiny-random_encoder_layer1_meta.json").exists()
+        assert tuple(torch.load(feats, weights_only=True).shape) == (300, 64)
+        assert not (tmp_path / "out").exists()  # extract-only: no training
+        cli.main(base)  # cache present: trains from it without a model
+        run = tmp_path / "out" / "n2_encoder_layer1"
+        assert (run / "final.pt").exists() and (run / "sae_final.pt").exists() and (run / "metrics.json").exists()
+        # one process, no files: extraction pushes into the ring the trainer samples
+        cfg["data"]["cache_dir"] = str(tmp_path / "cache2")
+        cfg["experiment_name"] = "n2ring"
+        (tmp_path / "cfg2.yaml").write_text(yaml.safe_dump(cfg))
+        cli.main(["--config", str(tmp_path / "cfg2.yaml"), "--no-wandb", "--device", str(device), "--mel", str(tmp_path / "mel.pt"),
+                  "--stream-to-ring"], whisper_model=tiny_whisper(0))
+        assert (tmp_path / "out" / "n2ring_encoder_layer1" / "final.pt").exists()
+        assert not list((tmp_path / "cache2" / "features").glob("*.pt"))
+        with pytest.raises(SystemExit):  # --extract-only without a model: this build never downloads one by name
+            cli.main(["--config", str(tmp_path / "cfg2.yaml"), "--no-wandb", "--device", str(device), "--extract-only"])

@@ -100,6 +100,9 @@ struct wsae_ctx {
     void* ent_hid;        // [maxB*K] relu(value) in the contraction dtype, bucket order
     void* ent_dpre;       // [maxB*K] dpre, bucket order
     int32_t* ent_off;     // [ceil(maxB/32)][ceil(H/128)+1] bucket boundaries
+    int ent_valid;        // 1: the last decode launch left the bucketed code of (ent_vals, ent_B) itself (chunked form)
+    const float* ent_vals;
+    int ent_B;
     int32_t* counters;    // small int scratch (fallback rows, resample cursors; [16..) = arrival tickets, 8-byte aligned)
     int32_t* dead_list;   // [H] compacted dead feature indices (resample)
     int32_t* row_order;   // [maxB] rows sorted by error (resample)

@@ -9,7 +9,8 @@
 
 #include "wsae_common.h"
 
-template <bool BWD>
+// NW = waves per block (the per-wave column sums in dbd_s are [NW][D])
+template <bool BWD, int NW = 4>
 __device__ __forceinline__ void decode_block_epilogue(float loss_acc, int l0_acc, const float* dbd_s, int D, int B,
                                                       int loss_cols, float* red, int* flag, float* part_loss, float* part_l0,
                                                       float* part_dbd, int32_t* ticket, wsae_stats* stats) {
@@ -21,8 +22,11 @@ __device__ __forceinline__ void decode_block_epilogue(float loss_acc, int l0_acc
         __hip_atomic_store(part_l0 + blockIdx.x, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (BWD) {
-        for (int d = threadIdx.x; d < D; d += 256)
-            part_dbd[(int64_t)blockIdx.x * D + d] = dbd_s[d] + dbd_s[D + d] + dbd_s[2 * D + d] + dbd_s[3 * D + d];
+        for (int d = threadIdx.x; d < D; d += 64 * NW) {
+            float a = (dbd_s[d] + dbd_s[D + d]) + (dbd_s[2 * D + d] + dbd_s[3 * D + d]);
+            if constexpr (NW == 8) a += (dbd_s[4 * D + d] + dbd_s[5 * D + d]) + (dbd_s[6 * D + d] + dbd_s[7 * D + d]);
+            part_dbd[(int64_t)blockIdx.x * D + d] = a;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -33,7 +37,7 @@ __device__ __forceinline__ void decode_block_epilogue(float loss_acc, int l0_acc
     __syncthreads();
     if (!*flag) return;
     float a = 0.f, c = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 64 * NW) {
         a += __hip_atomic_load(part_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c += __hip_atomic_load(part_l0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

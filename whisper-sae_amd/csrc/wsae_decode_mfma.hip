@@ -118,15 +118,22 @@ __host__ __device__ constexpr int dm_wave_bytes(int KS, int D) {
 
 // KS = MFMA k-steps of 32 feature slots (k <= 32: 1, k <= 64: 2), NSUB = D / 128, XDT = element type of x.
 // Two workgroups per CU (two waves per SIMD, <= 256 VGPRs) while their LDS allows it: k <= 32 and D <= 384.
-template <int KS, int NSUB, int XDT, bool BWD>
-__global__ void __launch_bounds__(256, (KS == 1 && NSUB <= 3) ? 2 : 1)
+// NW = 4: one resident round of 256-thread blocks, rows dealt round-robin over all waves of the grid.
+// NW = 8 ("chunked", backward only): one 512-thread block per 64-row chunk of the batch - the chunk the weight-gradient
+// contraction walks (wsae_wgrad.hip) - each wave takes 8 of its rows; when the rows are done the block counting-sorts the
+// chunk's K * 64 code entries by feature tile (what bucket_sort_kernel would do in a launch of its own: ent_pos / ent_hid /
+// ent_dpre / ent_off), reading back the dpre values its own waves have just stored (same CU, behind a barrier).
+template <int KS, int NSUB, int XDT, bool BWD, int NW>
+__global__ void __launch_bounds__(64 * NW, (KS == 1 && NSUB <= 3) ? 2 : 1)
 decode_mfma_kernel(const bf16_t* __restrict__ WdT, const float* __restrict__ bd, const float* __restrict__ bpre,
                    const void* __restrict__ x, const int32_t* __restrict__ rows, const float* __restrict__ vals,
                    const int32_t* __restrict__ idx, int B, int K, float* __restrict__ recon_out, float* __restrict__ dpre,
                    float* __restrict__ g32_out, bf16_t* __restrict__ gb_out, int64_t* __restrict__ last_activated,
                    float* __restrict__ fired, const int64_t* __restrict__ step_count, float* __restrict__ part_loss,
                    float* __restrict__ part_l0, float* __restrict__ part_dbd, int32_t* __restrict__ ticket,
-                   wsae_stats* __restrict__ stats, int loss_cols) {
+                   wsae_stats* __restrict__ stats, int loss_cols, int ntiles, int tw, uint32_t* __restrict__ ent_pos,
+                   bf16_t* __restrict__ ent_hid, bf16_t* __restrict__ ent_dpre, int32_t* __restrict__ ent_off) {
+    static_assert(NW == 4 || (NW == 8 && BWD), "the chunked form exists for the training backward only");
     constexpr int D = 128 * NSUB;
     constexpr int KP = 32 * KS;      // feature slots per row (K padded)
     constexpr int E = KP / 4;        // DMA wave-instructions per piece
@@ -143,9 +150,9 @@ decode_mfma_kernel(const bf16_t* __restrict__ WdT, const float* __restrict__ bd,
     char* code = wbase + 2 * SLOT;                            // [2 buffers][vals KP f32 | idx KP i32]
     bf16_t* grow = (bf16_t*)(code + 2 * 2 * KP * 4);          // [D] bf16(g) of the current row
     float* stage = (float*)(grow + D);                        // [128] sums of the current piece
-    float* red = (float*)(smem + 4 * WAVE_BYTES);             // [8]
+    float* red = (float*)(smem + NW * WAVE_BYTES);            // [8]
     int* flag_s = (int*)(red + 8);                            // [4]
-    float* dbd_s = (float*)smem;                              // [4][D] at the end (aliases the slots)
+    float* dbd_s = (float*)smem;                              // [NW][D] at the end (aliases the slots)
     const uint32_t slot_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)slot0;
 
     for (int i = lane; i < 2 * 2 * KP; i += 64) ((int*)code)[i] = 0;  // padded slots: value 0, feature 0
@@ -215,14 +222,16 @@ decode_mfma_kernel(const bf16_t* __restrict__ WdT, const float* __restrict__ bd,
         dma_piece<E>(WdT, off, slot_lds + slot * SLOT);
     };
 
-    const int b_first = blockIdx.x * 4 + wave, b_step = gridDim.x * 4;
+    const int b_first = NW == 8 ? blockIdx.x * 64 + wave : blockIdx.x * 4 + wave;
+    const int b_step = NW == 8 ? 8 : gridDim.x * 4;
+    const int b_end = NW == 8 ? min(B, (int)blockIdx.x * 64 + 64) : B;  // chunked: this block's rows end with its chunk
     int buf = 0, par = 0;  // code buffer of the current row; slot of its first piece
     int64_t src_next = 0;  // source row of the next batch row (ring gather), fetched one row ahead
     uint32_t rowp[E];
 #ifdef WSAE_DM_STAMPS
     unsigned long long dm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dm_last = __builtin_amdgcn_s_memtime();
 #endif
-    if (b_first < B) {
+    if (b_first < b_end) {
         src_next = rows ? (int64_t)rows[b_first] : (int64_t)b_first;
         get_code(b_first, 0);
         sources(0, rowp);
@@ -230,10 +239,10 @@ decode_mfma_kernel(const bf16_t* __restrict__ WdT, const float* __restrict__ bd,
         if (NSUB > 1) issue(rowp, 1, 1);
     }
     DM_T(0)
-    for (int b = b_first; b < B; b += b_step) {
+    for (int b = b_first; b < b_end; b += b_step) {
         const float* vs = (const float*)(code + buf * 2 * KP * 4);
         const int32_t* is = (const int32_t*)(vs + KP);
-        const bool more = b + b_step < B;
+        const bool more = b + b_step < b_end;
         // ---- dead-feature clock, l0 (model.py:148, :178-181): lane j looks at feature slot j ----
         {
             const float v = lane < KP ? vs[lane < KP ? lane : 0] : 0.f;
@@ -412,12 +421,70 @@ decode_mfma_kernel(const bf16_t* __restrict__ WdT, const float* __restrict__ bd,
 
     vm_wait<0>();
     __syncthreads();  // every wave is done with its slots: they become the per-wave column sums of g
+    if constexpr (NW == 8) {
+        // ---- counting sort of this chunk's code by feature tile (the bucket launch of wsae_wgrad.hip, fused) ----
+        // entries are fetched once, up front; the dpre values are this block's own stores (same CU's L1, behind the barrier)
+        int* cnt = (int*)smem;              // [ntiles <= 512]   (the slots are free now)
+        int* cur = cnt + 512;
+        constexpr int EB = 8;               // 512 threads x 8 >= 64 rows x K <= 64
+        const int tid = threadIdx.x;
+        const int c0 = (int)blockIdx.x * 64;
+        const int nent = (b_end - c0) * K;
+        const int64_t base = (int64_t)c0 * K;
+        int f[EB], tl[EB];
+        float v[EB], dp[EB];
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            const int e = min(tid + 512 * j, nent - 1);
+            f[j] = idx[base + e];
+            v[j] = vals[base + e];
+            dp[j] = dpre[base + e];
+        }
+        for (int t = tid; t < ntiles; t += 512) cnt[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            tl[j] = f[j] / tw;
+            if (tid + 512 * j < nent) atomicAdd(&cnt[tl[j]], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {  // exclusive scan over tiles by one wave
+            int carry = 0;
+            for (int t0 = 0; t0 < ntiles; t0 += 64) {
+                const int t = t0 + tid;
+                const int c = t < ntiles ? cnt[t] : 0;
+                int incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int nn = __shfl_up(incl, o, 64);
+                    if (tid >= o) incl += nn;
+                }
+                if (t < ntiles) {
+                    cur[t] = carry + incl - c;
+                    ent_off[(int64_t)blockIdx.x * (ntiles + 1) + t] = (int)base + carry + incl - c;
+                }
+                carry += __shfl(incl, 63, 64);
+            }
+            if (tid == 0) ent_off[(int64_t)blockIdx.x * (ntiles + 1) + ntiles] = (int)base + carry;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EB; ++j) {
+            const int e = tid + 512 * j;
+            if (e >= nent) continue;
+            const int p = atomicAdd(&cur[tl[j]], 1);
+            ent_pos[base + p] = ((uint32_t)(f[j] - tl[j] * tw) << 16) | (uint32_t)(e / K);
+            ent_hid[base + p] = (bf16_t)(v[j] > 0.f ? v[j] : 0.f);
+            ent_dpre[base + p] = (bf16_t)dp[j];
+        }
+        __syncthreads();  // cnt / cur alias the column-sum rows written next
+    }
     if (BWD) {
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) *(float2*)(dbd_s + wave * D + 128 * s + 2 * lane) = make_float2(dbd[s][0], dbd[s][1]);
     }
     __syncthreads();
-    decode_block_epilogue<BWD>(loss_acc, l0_acc, dbd_s, D, B, loss_cols, red, flag_s, part_loss, part_l0, part_dbd, ticket, stats);
+    decode_block_epilogue<BWD, NW>(loss_acc, l0_acc, dbd_s, D, B, loss_cols, red, flag_s, part_loss, part_l0, part_dbd, ticket, stats);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -429,19 +496,40 @@ static int resident_per_cu(F kernel, size_t sh) {
     return n;
 }
 
+// tiling of the weight-gradient contraction that will consume the bucketed code (wsae_wgrad.hip)
+void wsae_internal_wgrad_tiling(const wsae_ctx* c, int* tile_width, int* ntiles);
+
 template <int KS, int NSUB, int XDT>
 static int dm_launch(wsae_ctx* c, const float* params, const void* x, const int32_t* rows, const float* vals,
                      const int32_t* idx, int B, float* recon, int want_bwd, float* dpre, float* g32, int64_t* last_activated,
                      const int64_t* step_count, wsae_stats* stats, hipStream_t st) {
     const size_t sh = 4 * (size_t)dm_wave_bytes(KS, 128 * NSUB) + 12 * 4;
-    static const int per_cu[2] = {resident_per_cu(decode_mfma_kernel<KS, NSUB, XDT, false>, sh),
-                                  resident_per_cu(decode_mfma_kernel<KS, NSUB, XDT, true>, sh)};
-    const int nblk = min(ceil_div(B, 4), min(per_cu[want_bwd ? 1 : 0] * c->cus, WSAE_MAX_PARTIALS));
+    static const int per_cu[2] = {resident_per_cu(decode_mfma_kernel<KS, NSUB, XDT, false, 4>, sh),
+                                  resident_per_cu(decode_mfma_kernel<KS, NSUB, XDT, true, 4>, sh)};
+    int tw = 0, ntiles = 0;
+    wsae_internal_wgrad_tiling(c, &tw, &ntiles);
 #define DM_ARGS c->WdT_bf16, params + c->off[3], params + c->off[4], x, rows, vals, idx, B, c->K, recon, dpre, g32, \
                 c->gb, last_activated, c->fired, step_count, c->part_loss, c->part_l0, c->part_dbd,                       \
-                c->counters + 16 + 2 * TICKET_WORDS, stats, c->loss_cols
-    if (want_bwd) decode_mfma_kernel<KS, NSUB, XDT, true><<<nblk, 256, sh, st>>>(DM_ARGS);
-    else decode_mfma_kernel<KS, NSUB, XDT, false><<<nblk, 256, sh, st>>>(DM_ARGS);
+                c->counters + 16 + 2 * TICKET_WORDS, stats, c->loss_cols, ntiles, tw, c->ent_pos, (bf16_t*)c->ent_hid,   \
+                (bf16_t*)c->ent_dpre, c->ent_off
+    // chunked form: training backward on batches that give every CU at least one 64-row chunk (below that the one-round
+    // form with rows dealt over all waves keeps more CUs busy) and at most one partial slot per chunk
+    const int nchunks = ceil_div(B, 64);
+    c->ent_valid = 0;
+    if constexpr (KS == 1 && NSUB <= 3) {
+        if (want_bwd && dpre && NSUB == 3 && nchunks >= c->cus && nchunks <= WSAE_MAX_PARTIALS && ntiles <= 512 &&
+            c->K * 64 <= 4096) {  // (D > 256: the contraction that reads the code row-major, wsae_wgrad.hip)
+            const size_t sh8 = 8 * (size_t)dm_wave_bytes(KS, 128 * NSUB) + 12 * 4;
+            decode_mfma_kernel<KS, NSUB, XDT, true, 8><<<nchunks, 512, sh8, st>>>(DM_ARGS);
+            c->ent_valid = 1;
+            c->ent_vals = vals;
+            c->ent_B = B;
+            return nchunks;
+        }
+    }
+    const int nblk = min(ceil_div(B, 4), min(per_cu[want_bwd ? 1 : 0] * c->cus, WSAE_MAX_PARTIALS));
+    if (want_bwd) decode_mfma_kernel<KS, NSUB, XDT, true, 4><<<nblk, 256, sh, st>>>(DM_ARGS);
+    else decode_mfma_kernel<KS, NSUB, XDT, false, 4><<<nblk, 256, sh, st>>>(DM_ARGS);
 #undef DM_ARGS
     return nblk;
 }

@@ -873,7 +873,9 @@ static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const
     // ... and, when no staging launch left xT (the encoder GEMM gathered the batch rows itself), of x as a third kind
     const int ntr = rm ? 0 : (ldT / 64) * ceil_div(ctx->D, 64);
     const int nxt = ctx->xT_valid ? 0 : ntr;
-    if (rm && KT * ctx->K <= 4096)
+    if (rm && ctx->ent_valid && ctx->ent_vals == vals && ctx->ent_B == B) {
+        // the decode launch of this batch sorted the code itself (chunked form, wsae_decode_mfma.hip): nothing to launch
+    } else if (rm && KT * ctx->K <= 4096)
         bucket_sort_kernel<T><<<nchunks, 1024, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, W2_M, ctx->ent_pos, (T*)ctx->ent_hid,
                                                         (T*)ctx->ent_dpre, ctx->ent_off);
     else
@@ -904,6 +906,15 @@ static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const
     else wgrad_kernel<T, 1><<<grid, 256, 2 * 2 * TILE_LDS_BYTES, st>>>(WG_ARGS);
 #undef WG_ARGS
     WSAE_PROF_END(ctx, WSAE_K_WGRAD, st);
+    ctx->ent_valid = 0;
+}
+
+// feature-tile width and count of the contraction wsae_weight_grads will run on this ctx (the chunked decode kernel sorts
+// the code for it)
+void wsae_internal_wgrad_tiling(const wsae_ctx* c, int* tile_width, int* ntiles) {
+    const bool v2 = c->D > 256;
+    *tile_width = v2 ? W2_M : TILE_M;
+    *ntiles = ceil_div(c->H, *tile_width);
 }
 
 extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
