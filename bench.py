@@ -105,8 +105,11 @@ def kernel_work(name: str, B: int, D: int, H: int, K: int) -> dict:
     return {"flops": 0.0, "bytes": 0.0, "bound": "hbm", "what": ""}
 
 
-def roofline_object(name: str, n: int, ms: float, B: int, traffic_rec) -> dict:
-    w = kernel_work(name, B, D_MODEL, HIDDEN, TOPK)
+def roofline_object(name: str, n: int, ms: float, B: int, traffic_rec, launches_per_step: int = 1) -> dict:
+    w = dict(kernel_work(name, B, D_MODEL, HIDDEN, TOPK))
+    if launches_per_step > 1:  # data parallel: the backward runs in two halves, each kernel's work splits evenly over its launches
+        w["flops"] /= launches_per_step
+        w["bytes"] /= launches_per_step
     t = ms / n * 1e-3
     tf = w["flops"] / t / 1e12
     gbs = w["bytes"] / t / 1e9
@@ -134,7 +137,9 @@ def main() -> None:
     ap.add_argument("--windows", type=int, default=9,
                     help="timed windows of --steps steps each; the median is reported (every window is listed: the first ~100 steps after an idle GPU run at a ramping clock)")
     ap.add_argument("--grad-exchange", choices=("auto", "fp32", "bf16"), default="auto",
-                    help="N > 1: dtype of the gradient all-reduce (auto = bf16 in the bf16 mode, fp32 in the fp32 mode)")
+                    help="N > 1: dtype of the gradient all-reduce; auto (the bench default) = bf16 in the bf16 mode, fp32 in the "
+                         "fp32 mode - named in the line's config.workload / config.grad_exchange; the library default "
+                         "(TrainingConfig.grad_exchange_dtype) is fp32")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel (adds event overhead)")
     ap.add_argument("--dims", type=int, nargs=3, metavar=("D", "H", "K"), default=None,
                     help="informational: other SAE dimensions (e.g. 768 12288 64 = BASELINE.json configs[3]); no roofline object")
@@ -275,12 +280,17 @@ def main() -> None:
 
         if headline:
             names = dict(prof)
+            halves = 2 if (world > 1 and N.lib().wsae_wgrad_parts_supported(handle)) else 1
+
+            def lps(name):
+                return halves if name in ("wgrad", "wgrad_reduce") else 1
+
             if dominant and dominant in names and names[dominant][0]:
-                roof = roofline_object(dominant, names[dominant][0], names[dominant][1], B, traffic_of(dominant))
+                roof = roofline_object(dominant, names[dominant][0], names[dominant][1], B, traffic_of(dominant), lps(dominant))
                 roof["selected_by"] = "longest average launch in the probe window (HIP events around every kernel)"
             src = prof if "wgrad" in prof else probe
             if "wgrad" in src and src["wgrad"][0]:
-                roof_wgrad = roofline_object("wgrad", src["wgrad"][0], src["wgrad"][1], B, traffic_of("wgrad"))
+                roof_wgrad = roofline_object("wgrad", src["wgrad"][0], src["wgrad"][1], B, traffic_of("wgrad"), lps("wgrad"))
                 roof_wgrad["kernel"] = "wgrad2_kernel<bf16>" if args.precision == "bf16" else "wgrad2_kernel<f32>"
                 roof_wgrad["measured_in"] = "timed windows" if src is prof else "probe window (events around every kernel)"
             if roof is None:
@@ -302,7 +312,8 @@ def main() -> None:
                                     f"TopKSAE {D_MODEL}->{HIDDEN} k={TOPK} train step, informational" if args.dims else
                                     "BASELINE.json configs[1]: TopKSAE 384->3072 k=32 train step") + ", synthetic "
                                    "activations resident in the HBM ring buffer" + ("" if world == 1 else
-                                   f" (configs[2]: DDP x{world}, RCCL grad all-reduce)"),
+                                   f" (configs[2]: DDP x{world}, RCCL all-reduce of the gradients on a {trainer.grad_exchange} wire "
+                                   f"in two halves, the first under the encoder half of the backward)"),
                        "batch_per_gpu": B, "global_batch": world * B, "ring_rows_per_gpu": args.ring_rows,
                        "lr": 1e-4, "clip": 1.0, "parallelism": f"dp{world}",
                        **({"grad_exchange": trainer.grad_exchange} if world > 1 else {})},

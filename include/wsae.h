@@ -172,6 +172,28 @@ int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t
                       const int32_t* rows, const float* vals, const int32_t* idx,
                       const float* dpre, int32_t B, float* grads, void* stream);
 
+/* ---- data parallel: the gradients go straight onto the exchange buffer -------------------------------------------
+ * (absent from the reference, which is single-process).  The WIRE is what the ranks
+ * all-reduce(SUM): `hidden_dim * input_dim` elements of dW_dT, then dW_e, db_e, db_d, db_pre (the rest of the pack) and
+ * the `hidden_dim` fired indicators of wsae_ctx_set_fired, P + hidden_dim elements of `wire_dtype` (WSAE_DT_F32: the exact
+ * data-parallel gradient; WSAE_DT_BF16: half the bytes over xGMI, every rank's gradient rounded once to bf16, the
+ * indicators - sums of at most world_size ones - exact).  The decoder matrix comes FIRST so that the two halves of the
+ * backward fill two contiguous ranges:
+ *   part = WSAE_PART_DECODER  contraction of dW_dT alone (split-K 16) + its reduction -> wire[0, H D)
+ *   part = WSAE_PART_ENCODER  contraction of dW_e alone + reduction + the three bias gradients + the indicators
+ *                             -> wire[H D, P + H)          (same batch, after the decoder part)
+ *   part = WSAE_PART_ALL      both contractions in one launch (the single-GPU geometry) -> the whole wire
+ * The caller starts the all-reduce of wire[0, H D) after the decoder part, on its communication stream, and it runs under
+ * the encoder part's contraction.  Halves need input_dim > 256 (wsae_wgrad_parts_supported); the gradient pack in
+ * `grads` form is NOT written by these calls: wsae_grads_unpack_wire produces it from the summed wire. */
+#define WSAE_PART_ALL (-1)
+#define WSAE_PART_DECODER 0
+#define WSAE_PART_ENCODER 1
+int wsae_wgrad_parts_supported(const wsae_ctx* ctx);
+int wsae_weight_grads_wire(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                           const int32_t* rows, const float* vals, const int32_t* idx, const float* dpre,
+                           int32_t B, int32_t part, void* wire, int32_t wire_dtype, void* stream);
+
 /* Copy of g = 2 (recon - x) / (B cols), fp32 [B, D], as left by the last wsae_decode_loss with want_bwd = 3: the
  * gradient of the loss w.r.t. the reconstruction (= minus its gradient w.r.t. the target; transcoder skip path). */
 int wsae_last_residual_grad(wsae_ctx* ctx, int32_t B, float* g_out, void* stream);
@@ -192,10 +214,14 @@ int wsae_input_grad(wsae_ctx* ctx, const float* params, const int32_t* idx, cons
  * last_activated (nullable) / step_count / dead_threshold: when given, stats->dead_count and
  *   stats->dead_ratio are written (get_dead_feature_ratio() of training.py:212).
  * All four buffers use the flat pack layout. */
-/* Data parallel with a bf16 wire: widen the summed buffer [gradient pack | fired] (n_total bf16 elements, a multiple
- * of 8) into the fp32 buffer wsae_adamw_step reads and leave the gradient part's squared-norm partials in the ctx, so
- * that the following wsae_adamw_step(norm_from_wgrad = 1, grad_scale = 1 / world) needs no norm pass of its own. */
-int wsae_grads_unpack_wire(wsae_ctx* ctx, const void* wire_bf16, int64_t n_total, float* grads_ext, void* stream);
+/* Data parallel: turn the SUMMED wire (layout above, P + hidden_dim elements of wire_dtype) into the fp32 buffer
+ * `grads_ext` = [gradient pack in pack order | fired] that wsae_adamw_step reads, and leave the gradient part's
+ * squared-norm partials in the ctx, so that the following wsae_adamw_step(norm_from_wgrad = 1, grad_scale = 1 / world)
+ * needs no norm pass of its own.  metrics_sum (nullable): float[2] = the ranks' summed (loss, l0) of this step; then
+ * stats->loss / stats->l0 are overwritten with their means over `world` ranks (the metric exchange is
+ * two scalars, off the critical path). */
+int wsae_grads_unpack_wire(wsae_ctx* ctx, const void* wire, int32_t wire_dtype, float* grads_ext,
+                           const float* metrics_sum, int32_t world, wsae_stats* stats, void* stream);
 int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads, float* exp_avg,
                     float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int32_t step, float max_norm, float grad_scale,

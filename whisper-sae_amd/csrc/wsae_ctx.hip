@@ -108,7 +108,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     const size_t o_cn = cv.take((size_t)H * 4);
     const size_t o_ct = cv.take((16 + 3 * 2 * TICKET_WORDS) * 4);  // 16 ints + three tickets (optimizer, decode, grad finish)
     const size_t o_ws = cv.take((size_t)WSAE_WGRAD_MAX_SPLIT * 2 * H * D * 4);
-    const size_t o_ds = cv.take((size_t)WSAE_WGRAD_MAX_SPLIT * H * 4);
+    const size_t o_ds = cv.take((size_t)2 * WSAE_WGRAD_MAX_SPLIT * H * 4);  // (16 splits when one matrix is contracted per launch)
     const size_t o_dp = cv.take((size_t)((H + 31) / 32) * D * 4);
     const size_t o_ep = cv.take((size_t)maxB * K * 4);
     const size_t o_eh = cv.take((size_t)maxB * K * 4);

@@ -19,21 +19,31 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
-// ---- data parallel, bf16 wire (whisper_sae/distributed.py): the summed bf16 buffer [gradient pack P | fired H] is
-// widened back into the fp32 buffer the optimizer reads and, in the same pass, the gradient part's sum of squares is
-// left in the norm partials - the separate 9.45 MB norm pass of the DDP step is gone (wsae_adamw_step with
-// norm_from_wgrad = 1 takes them).  8 values per thread and trip; fixed reduction order.
-__global__ void __launch_bounds__(256) wire_unpack_kernel(const bf16_t* __restrict__ wire, int64_t n8, int64_t p8,
-                                                          float* __restrict__ out, float* __restrict__ part) {
+// ---- data parallel (whisper_sae/distributed.py): the summed wire [W_dT | W_e | b_e | b_d | b_pre | fired] (fp32 or bf16)
+// becomes the fp32 buffer the optimizer reads, [pack order: W_e | W_dT | b_e | b_d | b_pre | fired], and in the same pass
+// the gradient part's sum of squares is left in the norm partials - the separate 9.45 MB norm pass of a DDP step is gone
+// (wsae_adamw_step with norm_from_wgrad = 1 takes them).  8 values per thread and trip; fixed reduction order.  The two
+// matrices swap places between the layouts (hd8 = H D / 8 groups each), the tail keeps its position.
+template <typename WT>
+__global__ void __launch_bounds__(256) wire_unpack_kernel(const WT* __restrict__ wire, int64_t n8, int64_t p8, int64_t hd8,
+                                                          float* __restrict__ out, float* __restrict__ part,
+                                                          const float* __restrict__ metrics_sum, float inv_world,
+                                                          wsae_stats* __restrict__ stats) {
     __shared__ float red[8];
     float a = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-        const bf16x8 v = ((const bf16x8*)wire)[i];
         float f[8];
+        if constexpr (sizeof(WT) == 2) {
+            const bf16x8 v = ((const bf16x8*)wire)[i];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
-        ((float4*)out)[2 * i] = make_float4(f[0], f[1], f[2], f[3]);
-        ((float4*)out)[2 * i + 1] = make_float4(f[4], f[5], f[6], f[7]);
+            for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+        } else {
+            const float4 v0 = ((const float4*)wire)[2 * i], v1 = ((const float4*)wire)[2 * i + 1];
+            f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+        }
+        const int64_t o = i < hd8 ? i + hd8 : (i < 2 * hd8 ? i - hd8 : i);  // wire group -> pack group
+        ((float4*)out)[2 * o] = make_float4(f[0], f[1], f[2], f[3]);
+        ((float4*)out)[2 * o + 1] = make_float4(f[4], f[5], f[6], f[7]);
         if (i < p8) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) a = fmaf(f[e], f[e], a);
@@ -41,16 +51,29 @@ __global__ void __launch_bounds__(256) wire_unpack_kernel(const bf16_t* __restri
     }
     const float t = block_sum(a, red);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
+    if (metrics_sum && stats && blockIdx.x == 0 && threadIdx.x == 0) {  // mean over the ranks of the per-rank batch means
+        stats->loss = metrics_sum[0] * inv_world;
+        stats->l0 = metrics_sum[1] * inv_world;
+    }
 }
 
-extern "C" int wsae_grads_unpack_wire(wsae_ctx* ctx, const void* wire_bf16, int64_t n_total, float* grads_ext, void* stream) {
-    WSAE_REQUIRE(ctx && wire_bf16 && grads_ext, "wsae_grads_unpack_wire: null argument");
-    WSAE_REQUIRE(n_total >= ctx->P && n_total % 8 == 0 && ctx->P % 8 == 0,
-                 "wsae_grads_unpack_wire: buffer of %lld elements (pack %lld): both must be multiples of 8", (long long)n_total,
-                 (long long)ctx->P);
+extern "C" int wsae_grads_unpack_wire(wsae_ctx* ctx, const void* wire, int32_t wire_dtype, float* grads_ext,
+                                      const float* metrics_sum, int32_t world, wsae_stats* stats, void* stream) {
+    WSAE_REQUIRE(ctx && wire && grads_ext, "wsae_grads_unpack_wire: null argument");
+    WSAE_REQUIRE(wire_dtype == WSAE_DT_F32 || wire_dtype == WSAE_DT_BF16, "wsae_grads_unpack_wire: unknown wire dtype %d", wire_dtype);
+    WSAE_REQUIRE(world >= 1, "wsae_grads_unpack_wire: world size %d", world);
+    const int64_t n_total = ctx->P + ctx->H, hd = (int64_t)ctx->H * ctx->D;
+    // (P = 2 H D + H + 2 D with H, D multiples of 32: every boundary of the layout is a multiple of 8)
+    WSAE_REQUIRE(n_total % 8 == 0 && ctx->P % 8 == 0 && hd % 8 == 0, "wsae_grads_unpack_wire: pack %lld not in groups of 8", (long long)ctx->P);
     const int64_t n8 = n_total / 8;
     const int nparts = (int)min((int64_t)WSAE_MAX_PARTIALS, ceil_div64(n8, 256));
-    wire_unpack_kernel<<<nparts, 256, 0, (hipStream_t)stream>>>((const bf16_t*)wire_bf16, n8, ctx->P / 8, grads_ext, ctx->part_sq);
+    hipStream_t st = (hipStream_t)stream;
+    if (wire_dtype == WSAE_DT_BF16)
+        wire_unpack_kernel<bf16_t><<<nparts, 256, 0, st>>>((const bf16_t*)wire, n8, ctx->P / 8, hd / 8, grads_ext, ctx->part_sq,
+                                                            metrics_sum, 1.f / (float)world, stats);
+    else
+        wire_unpack_kernel<float><<<nparts, 256, 0, st>>>((const float*)wire, n8, ctx->P / 8, hd / 8, grads_ext, ctx->part_sq,
+                                                           metrics_sum, 1.f / (float)world, stats);
     WSAE_LAUNCH_CHECK();
     ctx->n_sq_parts = nparts;
     return WSAE_OK;

@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(W2_THREADS)
 wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hid, const T* __restrict__ ent_dpre,
               const int32_t* __restrict__ ent_off, const T* __restrict__ xT, const T* __restrict__ gT, int B, int ldT,
               int H, int D, int nsplit, int ntm, int ntn, float* __restrict__ out, int64_t slab_stride,
-              float* __restrict__ dbe_slab, const int32_t* __restrict__ xrows, int which0) {
+              float* __restrict__ dbe_slab, const int32_t* __restrict__ xrows, int which0, int nslots, int dec_row_base) {
     static_assert(!RM || sizeof(T) == 2, "the row-major operand path is the bf16 one (16-bit transposed LDS reads)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = SWZ_ROW_BYTES / (int)sizeof(T);
@@ -571,9 +571,10 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
         __syncthreads();
     }
 
-    // slab layout [row of the 2H x D matrix][split][D]: the 8 partial rows grad_finish sums are one contiguous 8 D run
-    const int64_t rstr = (int64_t)WSAE_WGRAD_MAX_SPLIT * D;
-    float* dst = out + (which == 0 ? (int64_t)H * rstr : 0) + (int64_t)split * D;
+    // slab layout [row][slot][D] (nslots slots per row: the partial rows grad_finish sums are one contiguous run); rows
+    // [0, H) = dW_e, the dW_dT rows start at dec_row_base (H when one launch holds both matrices, 0 when it holds one)
+    const int64_t rstr = (int64_t)nslots * D;
+    float* dst = out + (which == 0 ? (int64_t)dec_row_base * rstr : 0) + (int64_t)split * D;
     const int col = lane & 31, rq = lane >> 5;
     if (f0 + W2_M <= H && d0 + W2_N <= D) {
         // Interior tiles: the accumulators go through an LDS patch (the stages are free now) and leave as 16-byte stores,
@@ -625,11 +626,12 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
 }
 
 // ------------------------------------------------------------------------------------------------
-// grad_finish_kernel: everything between the split-K contraction and the optimizer, in ONE launch of
-// three kinds of blocks (they share nothing, so they share the launch instead of queueing behind each
+// grad_finish_kernel: everything between the split-K contraction and the optimizer (or the data-parallel exchange), in
+// ONE launch of three kinds of blocks (they share nothing, so they share the launch instead of queueing behind each
 // other's tails):
-//   [0, nrb)               grads[W parts] = sum over splits of the slabs (fixed order); db_e likewise; in
-//                          BF16 mode the rank-1 correction of the folded pre-bias on the way:
+//   [0, nrb)               out[W rows] = sum over splits of the slabs (fixed order) for the rows [row0, row0 + nrows) of the
+//                          [2 H][D] gradient matrix (rows < H: dW_e, the rest dW_dT); db_e likewise; in BF16 mode the rank-1
+//                          correction of the folded pre-bias on the way:
 //                              dW_e[h,:] -= db_e[h] * b_pre   (the MFMA contraction saw raw x, not x - b_pre)
 //                          and the block's share of the global-norm partials;
 //   [nrb, nrb + nblk_h)    db_pre partials  part[blk][d] = sum_{h in blk's 128 rows} db_e[h] * W_e[h][d]
@@ -641,16 +643,39 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
 // the partial rows are agent-scope (write-through) atomic stores drained with vmcnt(0) before the ticket
 // and read back with agent-scope atomic loads.  No float atomics anywhere: every sum has a fixed order.
 // Loads are issued in batches: a one-at-a-time loop here is pure L2 latency.
+//
+// The OUTPUT is addressed through five offsets (GfOut) and an element type OT, so the same kernel writes
+//   * the fp32 gradient buffer in pack order [W_e | W_dT | b_e | b_d | b_pre] (single process), or
+//   * the data-parallel WIRE buffer [W_dT | W_e | b_e | b_d | b_pre | fired] in fp32 or bf16 (include/wsae.h): the decoder
+//     matrix first, so that the launch that reduces the decoder half (bias kinds absent: do_bias = 0) fills ONE contiguous
+//     range whose all-reduce can start while the encoder half is still being contracted; the encoder launch fills the
+//     rest, copying the fired indicators behind the biases.
+// NS = slab slots per row (8: both matrices in one contraction launch; 16: one matrix per launch, split-K 16).
 // ------------------------------------------------------------------------------------------------
 #define DBPRE_ROWS 128
 #define DBD_L1 16
-template <typename TW, bool FOLD>
+struct GfOut {
+    int64_t oWe, oWd, oBe, oBd, oBp, oFired;
+};
+
+template <typename OT>
+__device__ __forceinline__ void gf_store4(OT* p, const float4& a) {
+    if constexpr (sizeof(OT) == 2) {
+        bf16x4 o;
+        o[0] = (bf16_t)a.x; o[1] = (bf16_t)a.y; o[2] = (bf16_t)a.z; o[3] = (bf16_t)a.w;
+        *(bf16x4*)p = o;
+    } else {
+        *(float4*)p = a;
+    }
+}
+
+template <typename TW, bool FOLD, typename OT, int NS>
 __global__ void __launch_bounds__(256)
-grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const float* __restrict__ dbe_slab, int nsplit,
-                   const float* __restrict__ bpre, float* __restrict__ grads, float* __restrict__ dbe_out, int H, int D,
-                   float* __restrict__ part_sq, int nrb, const TW* __restrict__ W, float* __restrict__ part, int nblk_h,
-                   const float* __restrict__ part_dbd, int n_dec, float* __restrict__ dbd2, float* __restrict__ dbd_out,
-                   float* __restrict__ dbpre_out, unsigned long long* __restrict__ ticket) {
+grad_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ dbe_slab, int nsplit,
+                   const float* __restrict__ bpre, OT* __restrict__ out, GfOut o, int H, int D, float* __restrict__ part_sq,
+                   int nrb, int row0, int nrows, int slab_row0, const TW* __restrict__ W, float* __restrict__ part,
+                   int nblk_h, const float* __restrict__ part_dbd, int n_dec, float* __restrict__ dbd2,
+                   unsigned long long* __restrict__ ticket, int do_bias, const float* __restrict__ fired_src) {
     __shared__ float red[8];
     __shared__ float e_s[DBPRE_ROWS];
     __shared__ __attribute__((aligned(16))) float p_s[1024];  // row-part sums of a db_pre block (D <= 512: parts x D <= 1024)
@@ -658,53 +683,59 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
     // the few latency-bound blocks (kinds two and three) take the first block ids so that they start
     // first and run under the streaming blocks instead of forming the tail of the launch
     const int tid = threadIdx.x;
-    const int nlat = nblk_h + DBD_L1;
+    const int nlat = do_bias ? nblk_h + DBD_L1 : 0;
     const int bid = (int)blockIdx.x >= nlat ? (int)blockIdx.x - nlat : nrb + (int)blockIdx.x;
     if (bid < nrb) {
-        // A wave owns `rpw` consecutive rows of the [2 H][D] gradient matrix (rows < H: dW_e, the rest dW_dT) and walks them
-        // two at a time as ONE contiguous range of float4 chunks: every slab load of up to TR full trips (8 splits x TR
-        // independent 16-byte loads per lane) is in flight before anything is summed.  (Row by row, a 96-chunk row is one
-        // full trip and one half-empty trip, each a separate round of memory latency: 22 us for 75 MB.)
-        static_assert(WSAE_WGRAD_MAX_SPLIT == 8, "the db_e gather below packs (row, split) into lane = 8 row + split");
-        constexpr int TR = 3;
+        // A wave owns `rpw` consecutive rows of its launch's row range and walks them two at a time as ONE contiguous range
+        // of float4 chunks: every slab load of up to TR full trips (NS splits x TR independent 16-byte loads per lane) is in
+        // flight before anything is summed.  (Row by row, a 96-chunk row is one full trip and one half-empty trip, each a
+        // separate round of memory latency: 22 us for 75 MB.)
+        static_assert(NS == 8 || NS == 16, "the db_e gather packs (row, split) into the lanes: 8 x 8 or 4 x 16");
+        constexpr int TR = NS == 8 ? 3 : 2;
         const int lane = tid & 63, wave = tid >> 6;
-        const int rows_total = 2 * H, nc = D >> 2;  // float4 chunks per row
-        const int rpw = (rows_total + nrb * 4 - 1) / (nrb * 4);
+        const int nc = D >> 2;  // float4 chunks per row
+        const int rpw = (nrows + nrb * 4 - 1) / (nrb * 4);
         float sq = 0.f;  // sum of squares of everything this block writes (global-norm partial)
         for (int q = 0; q < rpw; q += 2) {
-            const int r0 = (bid * 4 + wave) * rpw + q;
-            if (r0 >= rows_total) break;
-            const int nr = min(2, min(rpw - q, rows_total - r0));
+            const int r0 = row0 + (bid * 4 + wave) * rpw + q;
+            if (r0 >= row0 + nrows) break;
+            const int nr = min(2, min(rpw - q, row0 + nrows - r0));
             // db_e[h] = sum over splits, in split order (the db_pre blocks below use the same order)
             float be[2] = {0.f, 0.f};
-            {
-                const int j = lane >> 3, sp = lane & 7;
+            if (r0 < H) {  // (only dW_e rows have one)
+                const int j = lane / NS, sp = lane % NS;
                 const float v = (j < nr && sp < nsplit && r0 + j < H) ? dbe_slab[(int64_t)sp * H + r0 + j] : 0.f;
 #pragma unroll
-                for (int s2 = 0; s2 < WSAE_WGRAD_MAX_SPLIT; ++s2) {
+                for (int s2 = 0; s2 < NS; ++s2) {
                     be[0] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), s2));
-                    be[1] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 8 + s2));
+                    be[1] += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), NS + s2));
                 }
                 if (lane == 0) {
 #pragma unroll
                     for (int j2 = 0; j2 < 2; ++j2)
                         if (j2 < nr && r0 + j2 < H) {
-                            dbe_out[r0 + j2] = be[j2];
+                            out[o.oBe + r0 + j2] = (OT)be[j2];
                             sq = fmaf(be[j2], be[j2], sq);
                         }
                 }
             }
             const int total = nr * nc;
-            const float4* base = (const float4*)slabs + (int64_t)r0 * WSAE_WGRAD_MAX_SPLIT * nc;  // [row][split][D]
+            const float4* base = (const float4*)slabs + (int64_t)(r0 - slab_row0) * NS * nc;  // [row][slot][D]
+            OT* orow[2];
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int r = r0 + j2;
+                orow[j2] = out + (r < H ? o.oWe + (int64_t)r * D : o.oWd + (int64_t)(r - H) * D);
+            }
             for (int c0 = 0; c0 < total; c0 += 64 * TR) {
-                float4 v[TR][WSAE_WGRAD_MAX_SPLIT];
+                float4 v[TR][NS];
 #pragma unroll
                 for (int t = 0; t < TR; ++t) {
                     const int idx = min(c0 + lane + 64 * t, total - 1);  // clamped: unconditional loads
                     const int jr = idx >= nc ? 1 : 0, cc = idx - jr * nc;
 #pragma unroll
-                    for (int sp = 0; sp < WSAE_WGRAD_MAX_SPLIT; ++sp)  // splits past nsplit re-read the last one (weight 0)
-                        v[t][sp] = base[(jr * WSAE_WGRAD_MAX_SPLIT + min(sp, nsplit - 1)) * nc + cc];
+                    for (int sp = 0; sp < NS; ++sp)  // splits past nsplit re-read the last one (weight 0)
+                        v[t][sp] = base[(jr * NS + min(sp, nsplit - 1)) * nc + cc];
                 }
 #pragma unroll
                 for (int t = 0; t < TR; ++t) {
@@ -712,7 +743,7 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
                     if (idx >= total) continue;
                     float4 a = v[t][0];
 #pragma unroll
-                    for (int sp = 1; sp < WSAE_WGRAD_MAX_SPLIT; ++sp) {
+                    for (int sp = 1; sp < NS; ++sp) {
                         const float w = sp < nsplit ? 1.f : 0.f;
                         a.x = fmaf(w, v[t][sp].x, a.x); a.y = fmaf(w, v[t][sp].y, a.y);
                         a.z = fmaf(w, v[t][sp].z, a.z); a.w = fmaf(w, v[t][sp].w, a.w);
@@ -723,13 +754,22 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
                         const float b1 = j ? be[1] : be[0];
                         a.x -= b1 * bp.x; a.y -= b1 * bp.y; a.z -= b1 * bp.z; a.w -= b1 * bp.w;
                     }
-                    ((float4*)grads)[(int64_t)r0 * nc + idx] = a;
+                    gf_store4<OT>((j ? orow[1] : orow[0]) + 4 * c, a);
                     sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
                 }
             }
         }
+        // data parallel: the fired indicators ride behind the biases on the wire (sums of at most world ones: exact in bf16)
+        if (fired_src) {
+            const int per = (H + nrb - 1) / nrb;
+            for (int i = tid; i < per; i += 256) {
+                const int h = bid * per + i;
+                if (h < H) out[o.oFired + h] = (OT)fired_src[h];
+            }
+        }
         const float t = block_sum(sq, red);
         if (tid == 0) part_sq[bid] = t;
+        if (!do_bias) return;  // (no ticket in a launch without the bias kinds: nobody finishes anything)
     } else if (bid < nrb + nblk_h) {
         // db_pre partial of DBPRE_ROWS feature rows.  Work item = (row part, group of 4 columns): every thread streams
         // its rows with 8/16-byte loads, 16 in flight; with D <= 512 the block's rows are split over 256 / (D / 4) parts
@@ -831,10 +871,10 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
         }
 #pragma unroll
         for (int i = 0; i < DBD_L1; ++i) sd += v[i];
-        const float p = sd - sp;
-        dbd_out[d] = sd;
-        dbpre_out[d] = p;
-        sq += sd * sd + p * p;
+        const float pp = sd - sp;
+        out[o.oBd + d] = (OT)sd;
+        out[o.oBp + d] = (OT)pp;
+        sq += sd * sd + pp * pp;
     }
     const float t = block_sum(sq, red);
     if (tid == 0) part_sq[nrb] = t;
@@ -844,69 +884,99 @@ grad_finish_kernel(const float* __restrict__ slabs, int64_t slab_stride, const f
 // ceil(tiles * nsplit / resident workgroups) rounds, so the kernel time goes like rounds * chunks per
 // split; every split also costs one slab written and re-read (the small per-split term).  At
 // H = 3072, D = 384, B = 16384 (wgrad2_kernel: 32 tiles, one workgroup per CU) this picks 8: 256 workgroups,
-// one round of 32 chunks.
-static int pick_nsplit(wsae_ctx* ctx, int tiles, int nchunks, int nt) {
+// one round of 32 chunks; one matrix per launch (16 tiles, max_split 16) gets 16.
+static int pick_nsplit(wsae_ctx* ctx, int tiles, int nchunks, int nt, int max_split) {
     const int resident = ctx->cus * (nt == 1 ? 2 : 1);  // LDS: 72 KB per workgroup at NT = 1, 108 / 144 KB above
     int best = 1;
     int64_t best_cost = INT64_MAX;
-    for (int ns = 1; ns <= WSAE_WGRAD_MAX_SPLIT; ++ns) {
+    for (int ns = 1; ns <= max_split; ++ns) {
         if (ns > 1 && nchunks / ns < 4) break;  // >= 4 chunks per split
-        const int64_t rounds = ceil_div(tiles * ns, resident);
+        const int64_t rounds = ceil_div64(tiles * ns, resident);
         const int64_t cost = rounds * ceil_div(nchunks, ns) * 16 + 24 * ns;  // 16ths of a chunk time; a slab ~ 1.5 chunks
         if (cost < best_cost) { best_cost = cost; best = ns; }
     }
     return best;
 }
 
+// geometry of one wsae_weight_grads call
+struct WgPlan {
+    int ldT, nchunks, nt, ntm, ntn, nsplit, nslots, nwhich, which0, dec_row_base;
+    bool v2, rm;
+};
+
+// part: WSAE_PART_ALL = both contractions in one launch (split-K <= 8, slab rows [0, 2 H)); WSAE_PART_DECODER / _ENCODER = one
+// matrix (split-K <= 16, slab rows [0, H)): the halves of a data-parallel step (include/wsae.h)
 template <typename T>
-static void launch_wgrad(wsae_ctx* ctx, dim3 grid, int nt, hipStream_t st, const float* vals, const int32_t* idx,
-                         const float* dpre, int B, int ldT, int nsplit, int ntm, int ntn, float* out,
-                         int64_t slab_stride, const void* x, const int32_t* rows) {
+static WgPlan plan_wgrad(wsae_ctx* ctx, int B, int part) {
+    WgPlan p;
+    const int D = ctx->D, H = ctx->H;
+    p.ldT = (B + 127) / 128 * 128;
+    p.nchunks = ceil_div(B, Mfma<T>::KT);
+    const int ncol = ceil_div(D, TILE_N);  // column groups per workgroup: all of D in one workgroup when D is 2 or 3 tiles wide
+    p.v2 = D > 256;                        // wgrad2_kernel (192 x 384 tiles) for wide inputs, the 128-feature kernel serves D <= 256
+    p.nt = p.v2 ? 0 : (ncol % 3 == 0) ? 3 : (ncol % 2 == 0) ? 2 : 1;
+    p.ntm = p.v2 ? ceil_div(H, W2_M) : ceil_div(H, TILE_M);
+    p.ntn = p.v2 ? ceil_div(D, W2_N) : ncol / p.nt;
+    p.nwhich = part == WSAE_PART_ALL ? 2 : 1;
+    p.which0 = part == WSAE_PART_ENCODER ? 1 : 0;
+    p.nslots = part == WSAE_PART_ALL ? WSAE_WGRAD_MAX_SPLIT : 2 * WSAE_WGRAD_MAX_SPLIT;
+    p.dec_row_base = part == WSAE_PART_ALL ? H : 0;
+    p.nsplit = pick_nsplit(ctx, p.ntm * p.ntn * p.nwhich, p.nchunks, p.nt, p.nslots);
+    p.rm = sizeof(T) == 2 && p.nt == 0 && ctx->g_is_bf16 && D % 8 == 0;
+    return p;
+}
+
+template <typename T>
+static void launch_wgrad(wsae_ctx* ctx, const WgPlan& p, hipStream_t st, const float* vals, const int32_t* idx,
+                         const float* dpre, int B, float* out, const void* x, const int32_t* rows, bool sort_code) {
     constexpr int KT = Mfma<T>::KT;
-    const int nchunks = ceil_div(B, KT);
+    const int nchunks = p.nchunks, ldT = p.ldT, ntm = p.ntm, nt = p.nt;
+    const int64_t slab_stride = 2 * (int64_t)ctx->H * ctx->D;
     // Row-major dense operands (wgrad2_kernel<bf16, RM>): g as the MFMA decode launch left it (gb), x as the staged batch
     // xb or - when the encoder GEMM gathered its rows itself - the caller's bf16 rows through the row list.  Then the
     // bucket launch is the counting sort alone: no g -> gT / x -> xT blocks.
-    const bool rm = sizeof(T) == 2 && nt == 0 && ctx->g_is_bf16 && ctx->D % 8 == 0;
-    WSAE_PROF_BEGIN(ctx, WSAE_K_BUCKET, st);
-    // otherwise: + the transposition of g (left row-major by the decode launch) as a second kind of block in the same launch
-    // ... and, when no staging launch left xT (the encoder GEMM gathered the batch rows itself), of x as a third kind
-    const int ntr = rm ? 0 : (ldT / 64) * ceil_div(ctx->D, 64);
-    const int nxt = ctx->xT_valid ? 0 : ntr;
-    if (rm && ctx->ent_valid && ctx->ent_vals == vals && ctx->ent_B == B) {
-        // the decode launch of this batch sorted the code itself (chunked form, wsae_decode_mfma.hip): nothing to launch
-    } else if (rm && KT * ctx->K <= 4096)
-        bucket_sort_kernel<T><<<nchunks, 1024, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, W2_M, ctx->ent_pos, (T*)ctx->ent_hid,
-                                                        (T*)ctx->ent_dpre, ctx->ent_off);
-    else
-    bucket_kernel<T><<<nchunks + ntr + nxt, 256, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, nt == 0 ? W2_M : TILE_M, ctx->ent_pos,
-                                                          (T*)ctx->ent_hid, (T*)ctx->ent_dpre, ctx->ent_off, nchunks, ctx->g,
-                                                          ctx->g_is_bf16 ? ctx->gb : nullptr, (T*)ctx->gT, ctx->D, ldT,
-                                                          (const bf16_t*)x, rows, (T*)ctx->xT);
-    WSAE_PROF_END(ctx, WSAE_K_BUCKET, st);
+    const bool rm = p.rm;
+    if (sort_code) {
+        WSAE_PROF_BEGIN(ctx, WSAE_K_BUCKET, st);
+        // otherwise: + the transposition of g (left row-major by the decode launch) as a second kind of block in the same launch
+        // ... and, when no staging launch left xT (the encoder GEMM gathered the batch rows itself), of x as a third kind
+        const int ntr = rm ? 0 : (ldT / 64) * ceil_div(ctx->D, 64);
+        const int nxt = ctx->xT_valid ? 0 : ntr;
+        if (rm && ctx->ent_valid && ctx->ent_vals == vals && ctx->ent_B == B) {
+            // the decode launch of this batch sorted the code itself (chunked form, wsae_decode_mfma.hip): nothing to launch
+        } else if (rm && KT * ctx->K <= 4096)
+            bucket_sort_kernel<T><<<nchunks, 1024, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, W2_M, ctx->ent_pos, (T*)ctx->ent_hid,
+                                                            (T*)ctx->ent_dpre, ctx->ent_off);
+        else
+            bucket_kernel<T><<<nchunks + ntr + nxt, 256, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, nt == 0 ? W2_M : TILE_M, ctx->ent_pos,
+                                                                  (T*)ctx->ent_hid, (T*)ctx->ent_dpre, ctx->ent_off, nchunks, ctx->g,
+                                                                  ctx->g_is_bf16 ? ctx->gb : nullptr, (T*)ctx->gT, ctx->D, ldT,
+                                                                  (const bf16_t*)x, rows, (T*)ctx->xT);
+        WSAE_PROF_END(ctx, WSAE_K_BUCKET, st);
+    }
+    const dim3 grid(p.ntm * p.ntn * p.nwhich * p.nsplit);
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD, st);
 #define WG_ARGS ctx->ent_pos, (const T*)ctx->ent_hid, (const T*)ctx->ent_dpre, ctx->ent_off, (const T*)ctx->xT, \
-                (const T*)ctx->gT, B, ldT, ctx->H, ctx->D, nsplit, ntm, ntn, out, slab_stride, ctx->dbe_slab
+                (const T*)ctx->gT, B, ldT, ctx->H, ctx->D, p.nsplit, ntm, p.ntn, out, slab_stride, ctx->dbe_slab
     if (nt == 0) {
+        bool done = false;
         if constexpr (sizeof(T) == 2) {
             if (rm) {
                 const T* xsrc = ctx->xT_valid ? (const T*)ctx->xb : (const T*)x;
                 wgrad2_kernel<T, true><<<grid, W2_THREADS, 2 * W2_STAGE, st>>>(
                     ctx->ent_pos, (const T*)ctx->ent_hid, (const T*)ctx->ent_dpre, ctx->ent_off, xsrc, (const T*)ctx->gb, B, ldT,
-                    ctx->H, ctx->D, nsplit, ntm, ntn, out, slab_stride, ctx->dbe_slab, ctx->xT_valid ? nullptr : rows, 0);
-            } else {
-                wgrad2_kernel<T, false><<<grid, W2_THREADS, 2 * W2_STAGE, st>>>(WG_ARGS, nullptr, 0);
+                    ctx->H, ctx->D, p.nsplit, ntm, p.ntn, out, slab_stride, ctx->dbe_slab, ctx->xT_valid ? nullptr : rows,
+                    p.which0, p.nslots, p.dec_row_base);
+                done = true;
             }
-        } else {
-            wgrad2_kernel<T, false><<<grid, W2_THREADS, 2 * W2_STAGE, st>>>(WG_ARGS, nullptr, 0);
         }
+        if (!done) wgrad2_kernel<T, false><<<grid, W2_THREADS, 2 * W2_STAGE, st>>>(WG_ARGS, nullptr, p.which0, p.nslots, p.dec_row_base);
     }
     else if (nt == 3) wgrad_kernel<T, 3><<<grid, 768, 2 * 4 * TILE_LDS_BYTES, st>>>(WG_ARGS);
     else if (nt == 2) wgrad_kernel<T, 2><<<grid, 512, 2 * 3 * TILE_LDS_BYTES, st>>>(WG_ARGS);
     else wgrad_kernel<T, 1><<<grid, 256, 2 * 2 * TILE_LDS_BYTES, st>>>(WG_ARGS);
 #undef WG_ARGS
     WSAE_PROF_END(ctx, WSAE_K_WGRAD, st);
-    ctx->ent_valid = 0;
 }
 
 // feature-tile width and count of the contraction wsae_weight_grads will run on this ctx (the chunked decode kernel sorts
@@ -917,55 +987,89 @@ void wsae_internal_wgrad_tiling(const wsae_ctx* c, int* tile_width, int* ntiles)
     *ntiles = ceil_div(c->H, *tile_width);
 }
 
-extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
-                                 const int32_t* rows, const float* vals, const int32_t* idx, const float* dpre,
-                                 int32_t B, float* grads, void* stream) {
-    WSAE_REQUIRE(ctx && params && vals && idx && dpre && grads, "wsae_weight_grads: null argument");
+template <typename TW, bool FOLD, typename OT>
+static void launch_grad_finish(wsae_ctx* ctx, const WgPlan& p, hipStream_t st, const float* bpre, OT* out, const GfOut& o,
+                               const TW* W, int part, const float* fired_src) {
+    const int H = ctx->H, D = ctx->D;
+    const int nrows = part == WSAE_PART_ALL ? 2 * H : H;
+    const int row0 = part == WSAE_PART_DECODER ? H : 0;
+    const int slab_row0 = part == WSAE_PART_DECODER ? H : 0;  // (one matrix per launch: its slab rows start at 0)
+    const int do_bias = part != WSAE_PART_DECODER;
+    // reduction blocks: 8 rows each (two per wave), more when nrows / 8 would exceed the number of norm-partial slots
+    const int nrb = (int)min((int64_t)WSAE_MAX_PARTIALS - 1, ceil_div64(nrows, 8));
+    const int nblk = ceil_div(H, DBPRE_ROWS);
+    unsigned long long* ticket = (unsigned long long*)(ctx->counters + 16 + 4 * TICKET_WORDS);
+    const int grid = nrb + (do_bias ? nblk + DBD_L1 : 0);
+#define GF_ARGS ctx->wg_slabs, ctx->dbe_slab, p.nsplit, bpre, out, o, H, D, ctx->part_sq, nrb, row0, nrows, slab_row0, W, \
+                ctx->dbpre_part, nblk, ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2, ticket, do_bias, fired_src
+    if (p.nslots == WSAE_WGRAD_MAX_SPLIT) grad_finish_kernel<TW, FOLD, OT, WSAE_WGRAD_MAX_SPLIT><<<grid, 256, 0, st>>>(GF_ARGS);
+    else grad_finish_kernel<TW, FOLD, OT, 2 * WSAE_WGRAD_MAX_SPLIT><<<grid, 256, 0, st>>>(GF_ARGS);
+#undef GF_ARGS
+    ctx->n_sq_parts = part == WSAE_PART_ALL ? nrb + 1 : 0;  // wsae_adamw_step(norm_from_wgrad = 1) sums these (halves: the wire unpack leaves the norm)
+}
+
+static int weight_grads_impl(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,
+                             const float* vals, const int32_t* idx, const float* dpre, int32_t B, int part, float* grads,
+                             void* wire, int wire_dtype, hipStream_t st) {
+    WSAE_REQUIRE(ctx && params && vals && idx && dpre, "wsae_weight_grads: null argument");
     // x is read only when the forward skipped the staging launch (then it must be the same bf16 batch)
     WSAE_REQUIRE(ctx->xT_valid || (x && x_dtype == WSAE_DT_BF16 && ctx->prec == WSAE_PREC_BF16),
                  "wsae_weight_grads: the forward of this batch left no staged x^T and x is not a bf16 buffer");
     WSAE_REQUIRE(B >= 1 && B <= ctx->maxB, "wsae_weight_grads: batch %d outside [1, %d]", B, ctx->maxB);
-    hipStream_t st = (hipStream_t)stream;
-    const int D = ctx->D, H = ctx->H;
-    const int ldT = (B + 127) / 128 * 128;
-    const int kt = ctx->prec == WSAE_PREC_BF16 ? 64 : 32;
-    const int nchunks = ceil_div(B, kt);
-    // column groups per workgroup: all of D in one workgroup when D is 2 or 3 tiles wide
-    const int ncol = ceil_div(D, TILE_N);
-    // nt = 0 selects wgrad2_kernel (192 x 384 tiles) for wide inputs, the 128-feature kernel serves D <= 256
-    const bool v2 = D > 256;
-    const int nt = v2 ? 0 : (ncol % 3 == 0) ? 3 : (ncol % 2 == 0) ? 2 : 1;
-    const int ntm = v2 ? ceil_div(H, W2_M) : ceil_div(H, TILE_M);
-    const int ntn = v2 ? ceil_div(D, W2_N) : ncol / nt;
-    const int nsplit = pick_nsplit(ctx, ntm * ntn * 2, nchunks, nt);
-    const int64_t slab_stride = 2 * (int64_t)H * D;
-    WSAE_REQUIRE(ntm <= BUCKET_MAX_TILES, "hidden_dim %d too large for the bucket pass (max %d)", H, BUCKET_MAX_TILES * 128);
-    dim3 grid(ntm * ntn * 2 * nsplit);
+    const int H = ctx->H;
+    const bool bf = ctx->prec == WSAE_PREC_BF16;
+    const WgPlan p = bf ? plan_wgrad<bf16_t>(ctx, B, part) : plan_wgrad<float>(ctx, B, part);
+    WSAE_REQUIRE(p.ntm <= BUCKET_MAX_TILES, "hidden_dim %d too large for the bucket pass (max %d)", H, BUCKET_MAX_TILES * 128);
+    WSAE_REQUIRE(part == WSAE_PART_ALL || p.nt == 0, "wsae_weight_grads_wire: one matrix per launch needs input_dim > 256 (ask "
+                 "wsae_wgrad_parts_supported)");
+    // the code is sorted once per batch: by the first launch that needs it (the decoder half, or the single launch)
+    const bool sort_code = part != WSAE_PART_ENCODER;
     float* out = ctx->wg_slabs;
-    if (ctx->prec == WSAE_PREC_BF16)
-        launch_wgrad<bf16_t>(ctx, grid, nt, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride, x, rows);
-    else
-        launch_wgrad<float>(ctx, grid, nt, st, vals, idx, dpre, B, ldT, nsplit, ntm, ntn, out, slab_stride, x, rows);
+    if (bf) launch_wgrad<bf16_t>(ctx, p, st, vals, idx, dpre, B, out, x, rows, sort_code);
+    else launch_wgrad<float>(ctx, p, st, vals, idx, dpre, B, out, x, rows, sort_code);
+    if (part != WSAE_PART_DECODER) ctx->ent_valid = 0;  // (the encoder half of the same batch still reads the sorted code)
     WSAE_LAUNCH_CHECK();
 
-    float* dbe = grads + ctx->off[2];
     const float* bpre = params + ctx->off[4];
-    // reduction blocks: 8 rows of the [2 H][D] gradient matrix each (two per wave), more when 2 H / 8 would exceed the
-    // number of norm-partial slots
-    const int nrb = (int)min((int64_t)WSAE_MAX_PARTIALS - 1, ceil_div64(2 * (int64_t)H, 8));
-    const int nblk = ceil_div(H, DBPRE_ROWS);
-    unsigned long long* ticket = (unsigned long long*)(ctx->counters + 16 + 4 * TICKET_WORDS);
+    const int64_t HD = (int64_t)H * ctx->D;
     WSAE_PROF_BEGIN(ctx, WSAE_K_WGRAD_REDUCE, st);
-#define GF_ARGS out, slab_stride, ctx->dbe_slab, nsplit, bpre, grads, dbe, H, D, ctx->part_sq, nrb
-#define GF_TAIL ctx->dbpre_part, nblk, ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2, grads + ctx->off[3], grads + ctx->off[4], ticket
-    if (ctx->prec == WSAE_PREC_BF16)
-        grad_finish_kernel<bf16_t, true><<<nrb + nblk + DBD_L1, 256, 0, st>>>(GF_ARGS, (const bf16_t*)ctx->We_bf16, GF_TAIL);
-    else
-        grad_finish_kernel<float, false><<<nrb + nblk + DBD_L1, 256, 0, st>>>(GF_ARGS, params + ctx->off[0], GF_TAIL);
-#undef GF_ARGS
-#undef GF_TAIL
+    if (!wire) {
+        const GfOut o = {ctx->off[0], ctx->off[1], ctx->off[2], ctx->off[3], ctx->off[4], 0};
+        if (bf) launch_grad_finish<bf16_t, true, float>(ctx, p, st, bpre, grads, o, (const bf16_t*)ctx->We_bf16, part, nullptr);
+        else launch_grad_finish<float, false, float>(ctx, p, st, bpre, grads, o, params + ctx->off[0], part, nullptr);
+    } else {
+        // wire order: [W_dT | W_e | b_e | b_d | b_pre | fired]
+        const GfOut o = {HD, 0, 2 * HD, 2 * HD + H, 2 * HD + H + ctx->D, ctx->P};
+        const float* fired = part != WSAE_PART_DECODER ? ctx->fired : nullptr;
+        if (wire_dtype == WSAE_DT_BF16) {
+            if (bf) launch_grad_finish<bf16_t, true, bf16_t>(ctx, p, st, bpre, (bf16_t*)wire, o, (const bf16_t*)ctx->We_bf16, part, fired);
+            else launch_grad_finish<float, false, bf16_t>(ctx, p, st, bpre, (bf16_t*)wire, o, params + ctx->off[0], part, fired);
+        } else {
+            if (bf) launch_grad_finish<bf16_t, true, float>(ctx, p, st, bpre, (float*)wire, o, (const bf16_t*)ctx->We_bf16, part, fired);
+            else launch_grad_finish<float, false, float>(ctx, p, st, bpre, (float*)wire, o, params + ctx->off[0], part, fired);
+        }
+        ctx->n_sq_parts = 0;  // the norm is taken from the summed wire (wsae_grads_unpack_wire)
+    }
     WSAE_PROF_END(ctx, WSAE_K_WGRAD_REDUCE, st);
     WSAE_LAUNCH_CHECK();
-    ctx->n_sq_parts = nrb + 1;  // wsae_adamw_step(norm_from_wgrad = 1) sums these
     return WSAE_OK;
+}
+
+extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                                 const int32_t* rows, const float* vals, const int32_t* idx, const float* dpre,
+                                 int32_t B, float* grads, void* stream) {
+    WSAE_REQUIRE(grads, "wsae_weight_grads: null gradient buffer");
+    return weight_grads_impl(ctx, params, x, x_dtype, rows, vals, idx, dpre, B, WSAE_PART_ALL, grads, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int wsae_wgrad_parts_supported(const wsae_ctx* ctx) { return (ctx && ctx->D > 256) ? 1 : 0; }
+
+extern "C" int wsae_weight_grads_wire(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
+                                      const int32_t* rows, const float* vals, const int32_t* idx, const float* dpre,
+                                      int32_t B, int32_t part, void* wire, int32_t wire_dtype, void* stream) {
+    WSAE_REQUIRE(wire && (wire_dtype == WSAE_DT_F32 || wire_dtype == WSAE_DT_BF16), "wsae_weight_grads_wire: bad wire buffer / dtype");
+    WSAE_REQUIRE(part == WSAE_PART_ALL || part == WSAE_PART_DECODER || part == WSAE_PART_ENCODER,
+                 "wsae_weight_grads_wire: part must be WSAE_PART_ALL, _DECODER or _ENCODER");
+    WSAE_REQUIRE(ctx && (part == WSAE_PART_DECODER || ctx->fired), "wsae_weight_grads_wire: set the fired buffer first (wsae_ctx_set_fired)");
+    return weight_grads_impl(ctx, params, x, x_dtype, rows, vals, idx, dpre, B, part, nullptr, wire, wire_dtype, (hipStream_t)stream);
 }

@@ -15,6 +15,7 @@ LIB_NAME = "libwsae_hip.so"
 
 PREC_BF16, PREC_FP32 = 0, 1
 DT_F32, DT_BF16 = 0, 1
+PART_ALL, PART_DECODER, PART_ENCODER = -1, 0, 1  # wsae_weight_grads_wire
 
 
 class WsaeError(RuntimeError):
@@ -65,7 +66,9 @@ SIGNATURES = {
     "wsae_weight_grads": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p]),
     "wsae_last_residual_grad": (C.c_int, [_p, _i32, _p, _p]),
     "wsae_input_grad": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i32, _p]),
-    "wsae_grads_unpack_wire": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "wsae_wgrad_parts_supported": (C.c_int, [_p]),
+    "wsae_weight_grads_wire": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p, _i32, _i32, _p, _i32, _p]),
+    "wsae_grads_unpack_wire": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _p, _p]),
     "wsae_adamw_step": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _i32,
                                   _p, _p, _i64, _p, _p]),
     "wsae_normalize_decoder": (C.c_int, [_p, _p, _p]),

@@ -78,11 +78,12 @@ class TrainingConfig(BaseModel):
     num_workers: int = Field(4, ge=0)
     resample_dead_every: int = Field(5000, ge=1)
     resample_batch_size: int = Field(8192, ge=1)
-    grad_exchange_dtype: str = Field("auto", pattern="^(auto|fp32|bf16)$",
+    grad_exchange_dtype: str = Field("fp32", pattern="^(auto|fp32|bf16)$",
                                      description="data-parallel runs only (not in the reference, which is single-process): "
-                                                 "dtype of the gradient all-reduce. auto = bf16 when use_amp (the gradient "
-                                                 "GEMMs already take bf16-rounded operands; half the bytes over xGMI), fp32 "
-                                                 "otherwise (the exact data-parallel gradient)")
+                                                 "dtype of the gradient all-reduce. fp32 (default) = the exact data-parallel "
+                                                 "gradient; bf16 = half the bytes over xGMI, every rank's gradient rounded "
+                                                 "once to bf16 and summed in bf16 (opt-in: it changes the step); auto = bf16 "
+                                                 "when use_amp, fp32 otherwise")
 
 
 class DataConfig(BaseModel):

@@ -6,12 +6,19 @@ average over their own B rows and then average the gradients reproduce exactly t
 concatenated N*B batch.  One process per GPU; ``torch.distributed`` backend ``"nccl"`` is RCCL on
 ROCm (xGMI inside a node); ``"gloo"`` runs the same code on CPU tensors for tests.
 
-Per step there is ONE collective: ``all_reduce(SUM)`` of the flat buffer ``[gradient pack | fired]``
-(9.45 MB + 12 KB at 384->3072 as fp32 - the fp32 mode - or half of that as bf16 - the bf16 mode's default; the
-1/world factor is folded into the fused optimizer kernel as ``grad_scale``).  ``fired[f]`` is 1.0 on the ranks where feature f fired in this step; its sum tells
-every rank which ``feature_last_activated`` entries to stamp with the current step, which equals an
-``all_reduce(MAX)`` of the clocks (clocks that agreed before the step either all advance to the step or
-all stay) without a second, latency-bound collective.
+The exchange buffer (the "wire", ``include/wsae.h``) is ``[dW_dT | dW_e | db_e | db_d | db_pre | fired]``, fp32 (the exact
+data-parallel gradient; the default) or bf16 (``TrainingConfig.grad_exchange_dtype = "bf16"``: half the bytes over xGMI);
+9.45 MB + 12 KB as fp32 at 384->3072.  The reduction kernel of the backward writes it directly - the decoder matrix first -
+and the trainer all-reduces it in TWO collectives, ``wire[:H D]`` as soon as the decoder half of the backward is done
+(it runs under the encoder half's contraction) and the rest after the encoder half (``SAETrainer._ddp_backward``); the
+1/world factor is folded into the fused optimizer kernel as ``grad_scale``.  ``fired[f]`` is 1.0 on the ranks where
+feature f fired in this step; its sum tells every rank which ``feature_last_activated`` entries to stamp with the current
+step, which equals an ``all_reduce(MAX)`` of the clocks (clocks that agreed before the step either all advance to the step
+or all stay) without another latency-bound collective.  The two metric scalars (loss, l0) are summed in an 8-byte
+collective of their own, issued before the backward: off the critical path.
+
+``WireExchange`` / ``pack_to_wire`` / ``wire_to_pack`` restate the host side of that protocol on plain tensors (CPU tests
+run it over gloo with oracle gradients; the trainer runs the same calls between its kernel launches).
 """
 
 from __future__ import annotations
@@ -54,6 +61,45 @@ def sync_gradients(flat: torch.Tensor, exchange_dtype: torch.dtype = torch.float
         else:
             flat.copy_(wire)
     return 1.0 / n
+
+
+def wire_offsets(input_dim: int, hidden_dim: int) -> dict:
+    """Element offsets of the wire layout ``[dW_dT | dW_e | db_e | db_d | db_pre | fired]`` (``include/wsae.h``)."""
+    hd = input_dim * hidden_dim
+    return {"W_dT": 0, "W_e": hd, "b_e": 2 * hd, "b_d": 2 * hd + hidden_dim, "b_pre": 2 * hd + hidden_dim + input_dim,
+            "fired": 2 * hd + hidden_dim + 2 * input_dim, "total": 2 * hd + 2 * hidden_dim + 2 * input_dim, "split": hd}
+
+
+def pack_to_wire(grads_ext: torch.Tensor, input_dim: int, hidden_dim: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """``[pack order: dW_e | dW_dT | biases | fired]`` -> wire order, in ``dtype`` (what the reduction kernel writes)."""
+    hd = input_dim * hidden_dim
+    return torch.cat([grads_ext[hd:2 * hd], grads_ext[:hd], grads_ext[2 * hd:]]).to(dtype)
+
+
+def wire_to_pack(wire: torch.Tensor, input_dim: int, hidden_dim: int) -> torch.Tensor:
+    """The summed wire back in pack order, fp32 (what ``wsae_grads_unpack_wire`` produces)."""
+    hd = input_dim * hidden_dim
+    return torch.cat([wire[hd:2 * hd], wire[:hd], wire[2 * hd:]]).float()
+
+
+class WireExchange:
+    """The collectives of one data-parallel step: ``start(view)`` issues an asynchronous ``all_reduce(SUM)`` of a slice
+    of the wire (the tensor must stay alive until ``finish``), ``finish()`` makes the current stream (RCCL) or the host
+    (gloo) wait for all of them.  Outside torch.distributed both are no-ops."""
+
+    def __init__(self):
+        self._works = []
+
+    def start(self, view: torch.Tensor) -> None:
+        dist, _ = world()
+        if dist is not None:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> float:
+        for wk in self._works:
+            wk.wait()
+        self._works.clear()
+        return 1.0 / world()[1]
 
 
 def merge_clock(last_activated: torch.Tensor, fired_sum: torch.Tensor, step: int) -> torch.Tensor:

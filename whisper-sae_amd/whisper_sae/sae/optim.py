@@ -42,7 +42,16 @@ class FusedAdamW(Optimizer):
         self.grads_ext = torch.zeros(eng.P + eng.H, dtype=torch.float32, device=eng.device)
         self.grads = self.grads_ext[:eng.P]
         self.fired = self.grads_ext[eng.P:]
+        self._wire = None
+        self.metric_buf = torch.zeros(2, dtype=torch.float32, device=eng.device)  # (loss, l0) summed over the ranks under DDP
         self._alias_state(eng)
+
+    def wire(self, dtype: torch.dtype) -> torch.Tensor:
+        """The data-parallel exchange buffer ``[dW_dT | dW_e | db_e | db_d | db_pre | fired]`` (include/wsae.h), P + H
+        elements of ``dtype``; allocated on first use, persistent so that asynchronous collectives may hold views of it."""
+        if self._wire is None or self._wire.dtype != dtype or self._wire.numel() != self.grads_ext.numel():
+            self._wire = torch.zeros(self.grads_ext.numel(), dtype=dtype, device=self.grads_ext.device)
+        return self._wire
 
     def _alias_state(self, eng) -> None:
         """Point every parameter's exp_avg / exp_avg_sq at its slice of the flat buffers, carrying

@@ -31,7 +31,7 @@ from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
 
 from .. import _native as N
 from ..config import TrainingConfig
-from ..distributed import barrier, rank_and_world, sync_gradients, world
+from ..distributed import WireExchange, barrier, rank_and_world, sync_gradients, world
 from .engine import _dtype_code, require_device_tensor
 from .model import relu_fp8_flag
 from .optim import FusedAdamW
@@ -246,24 +246,14 @@ class SAETrainer:
         N.check(lib.wsae_encode_decode(handle, pk, x.data_ptr(), xd, rp, B, w["vals"].data_ptr(), w["idx"].data_ptr(),
                                        step_ptr, 0, 1, w["dpre"].data_ptr(), model.feature_last_activated.data_ptr(),
                                        stats, st), "wsae_encode_decode")
-        N.check(lib.wsae_weight_grads(handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(),
-                                      w["dpre"].data_ptr(), B, opt.grads.data_ptr(), st), "wsae_weight_grads")
-        eng.generation += 1
-        # data parallel: ONE RCCL all-reduce of [gradients | fired indicators]; the optimizer kernel applies
-        # 1/world and stamps the dead-feature clock of every feature that fired on any rank
-        fused_norm = True  # the norm partials come with the gradients: from wsae_weight_grads, or from the wire unpack
-        if ddp:
-            unpack = None
-            if self._exchange_dtype == torch.bfloat16 and opt.grads_ext.numel() % 8 == 0 and eng.P % 8 == 0:
-                def unpack(wire, _h=handle, _g=opt.grads_ext):
-                    N.check(lib.wsae_grads_unpack_wire(_h, wire.data_ptr(), wire.numel(), _g.data_ptr(), eng.stream()),
-                            "wsae_grads_unpack_wire")
-                    wire.record_stream(torch.cuda.current_stream(eng.device))
-            else:
-                fused_norm = False  # the norm has to be taken after the all-reduce: one more pass over the gradients
-            grad_scale = sync_gradients(opt.grads_ext, self._exchange_dtype, unpack)
-        else:
+        if not ddp:
+            N.check(lib.wsae_weight_grads(handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(),
+                                          w["dpre"].data_ptr(), B, opt.grads.data_ptr(), st), "wsae_weight_grads")
             grad_scale = 1.0
+        else:
+            grad_scale = self._ddp_backward(eng, handle, opt, x, xd, rp, w, B, chunk, slot, stats, st)
+        eng.generation += 1
+        fused_norm = True  # the norm partials come with the gradients: from wsae_weight_grads, or from the wire unpack
         opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=grad_scale,
                  normalize_decoder=True, batch=B, norm_from_wgrad=fused_norm, dead_scan=True,
                  stats_ptr=stats)
@@ -276,6 +266,45 @@ class SAETrainer:
         if self.resample_dead:
             self._maybe_resample_dead_features()
         return metrics
+
+    def _ddp_backward(self, eng, handle, opt, x, xd, rp, w, B, chunk, slot, stats, st) -> float:
+        """Data-parallel backward (the reference is single-process): the weight gradients are
+        produced in two halves that land on the exchange buffer ("wire", include/wsae.h) directly, and each half's
+        all-reduce is started - asynchronously, on the process group's own stream - as soon as its half is there:
+
+            decoder contraction + reduction -> wire[0, HD)      | all-reduce A starts
+            encoder contraction + reduction + biases + fired -> wire[HD, P+H)   (A runs underneath)   | all-reduce B starts
+            wait A, B -> one pass turns the summed wire into the fp32 gradient pack + norm partials -> optimizer
+
+        ONE collective per half; only B (and what is left of A) is exposed.  The two metric scalars (loss, l0: per-rank
+        batch means) travel in a third, 8-byte all-reduce issued before the backward starts - off the critical path - and
+        their mean over the ranks replaces the local values in the step record.  No torch compute op: the wire is written
+        by the reduction kernel in its dtype (fp32, or bf16 = half the bytes; ``TrainingConfig.grad_exchange_dtype``).
+        Returns the factor for the summed gradients (1 / world)."""
+        dist, nranks = world()
+        lib = eng.lib
+        wire_dt = N.DT_BF16 if self._exchange_dtype == torch.bfloat16 else N.DT_F32
+        wire = opt.wire(self._exchange_dtype)
+        hd = eng.H * eng.D
+        pk = eng.pack.data_ptr()
+        # metric scalars of this step (the decode launch has written them): summed over the ranks beside the gradients
+        met = opt.metric_buf
+        met.copy_(chunk.dev[slot].view(torch.float32)[:2], non_blocking=True)
+        ex = WireExchange()
+        ex.start(met)
+        args = (handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(), w["dpre"].data_ptr(), B)
+        if lib.wsae_wgrad_parts_supported(handle):
+            N.check(lib.wsae_weight_grads_wire(*args, N.PART_DECODER, wire.data_ptr(), wire_dt, st), "wsae_weight_grads_wire")
+            ex.start(wire[:hd])
+            N.check(lib.wsae_weight_grads_wire(*args, N.PART_ENCODER, wire.data_ptr(), wire_dt, st), "wsae_weight_grads_wire")
+            ex.start(wire[hd:])
+        else:  # narrow inputs (one launch holds both contractions): one collective over the whole wire
+            N.check(lib.wsae_weight_grads_wire(*args, N.PART_ALL, wire.data_ptr(), wire_dt, st), "wsae_weight_grads_wire")
+            ex.start(wire)
+        scale = ex.finish()  # (RCCL: the compute stream waits for the collectives; the host does not)
+        N.check(lib.wsae_grads_unpack_wire(handle, wire.data_ptr(), wire_dt, opt.grads_ext.data_ptr(), met.data_ptr(), nranks,
+                                           stats, st), "wsae_grads_unpack_wire")
+        return scale
 
     def _train_step_relu(self, model, eng, handle, opt, x, rows, B, prec) -> TrainingMetrics:
         """ReLU + L1 step (reference ReLUSAE under training.py:161-217; no dead-feature bookkeeping)."""
@@ -365,9 +394,11 @@ class SAETrainer:
             "config": self.config.model_dump(),
         }
         tmp = target.with_name(target.name + ".tmp")
-        torch.save(payload, tmp)
-        tmp.replace(target)  # atomic on POSIX: a reader sees the old file or the new one
-        barrier()
+        try:
+            torch.save(payload, tmp)
+            tmp.replace(target)  # atomic on POSIX: a reader sees the old file or the new one
+        finally:
+            barrier()  # reached even when the write raises (disk full, bad run_dir): the other ranks must not hang at theirs
         return target
 
     def load_checkpoint(self, path) -> None:
@@ -381,7 +412,7 @@ class SAETrainer:
 
     def save_metrics(self, filename: str = "metrics.json") -> Path:
         target = self.run_dir / filename
-        if rank_and_world()[0] != 0:  # rank 0's history is the run's history (metrics are per-rank batch means)
+        if rank_and_world()[0] != 0:  # rank 0's history is the run's history (loss / l0 are already means over the ranks)
             return target
         keys = ("step", "loss", "reconstruction_loss", "sparsity_loss", "l0", "dead_feature_ratio", "learning_rate")
         rows = [{k: getattr(m, k) for k in keys} for m in self.metrics_history]
