@@ -333,6 +333,11 @@ int wsae_feature_topk_update(const float* vals, const int32_t* idx, int64_t rows
  * mode only; hidden, loss and the whole backward stay on the bf16 path.  Needs batch >= 512, input_dim % 256 == 0,
  * hidden_dim % 256 == 0. */
 int wsae_ctx_set_relu_fp8(wsae_ctx* ctx, int32_t on);
+/* 1 when wsae_relu_forward / wsae_relu_backward at batch size B read / write the dense fp32 `hidden` buffer, 0 when it is
+ * optional (bf16 mode, whole 128-row groups, input_dim a multiple of 128, hidden_dim of 256: the hidden code then lives as
+ * bf16 in the ctx workspace, written by the encoder GEMM's epilogue, and `hidden` may be NULL - a trainer that never looks at
+ * it saves 4 B H bytes of stores per step; a non-NULL `hidden` still receives the fp32 copy). */
+int wsae_relu_needs_hidden(const wsae_ctx* ctx, int32_t B);
 /* Per-feature weights w[hidden_dim] of the L1 term (device memory, caller-owned, must outlive the calls; NULL = all ones, the
  * default): the sparsity term of wsae_relu_forward becomes sum_b sum_s w[s] |hidden[b][s]| / (B H) and wsae_relu_backward adds
  * sparsity_weight * w[s] / (B H) to dL/dhidden[b][s] (w itself is a constant of the step).  The cross-layer crosscoder

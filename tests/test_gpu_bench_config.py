@@ -321,11 +321,12 @@ class TestConfigs4:
     bf16 mode against the float64 oracle's forward / backward on the same weights (ragged batch: the persistent
     split-K GEMMs with a partly filled last tile)."""
 
-    def test_relu_step_at_1280_40960(self, device, tmp_path):
+    @pytest.mark.parametrize("B", [600, 512])  # 600: ragged (general path); 512: the row-major-GEMM flow, no fp32 hidden at all
+    def test_relu_step_at_1280_40960(self, device, tmp_path, B):
         from whisper_sae.config import TrainingConfig
         from whisper_sae.sae.model import ReLUSAE
         from whisper_sae.sae.training import SAETrainer
-        D, H, B, weight = 1280, 40960, 600, 0.01
+        D, H, weight = 1280, 40960, 0.01
         w = synth.sae_weights(D, H, seed=17, bf16=True)
         m = ReLUSAE(D, H, sparsity_weight=weight)
         sd = m.state_dict()
@@ -350,6 +351,6 @@ class TestConfigs4:
             got, want = cpu(tr.optimizer.grad_view(key)).astype(np.float64), gr[n].astype(np.float64)
             d[n] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
             assert d[n] < 2e-2, (n, d[n])
-        note("cfg5_relu_B600", {"d_loss": d_loss, "d_l1": d_l1, "grad_rel_l2": d})
+        note(f"cfg5_relu_B{B}", {"d_loss": d_loss, "d_l1": d_l1, "grad_rel_l2": d})
         cn = m.decoder.weight.detach().norm(dim=0)
         assert torch.allclose(cn, torch.ones_like(cn), atol=1e-5)

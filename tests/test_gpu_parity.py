@@ -395,8 +395,12 @@ class TestReLUSAE:
                        (m.decoder.bias, "db_d")):
             assert rel(cpu(p.grad), g[key]) < 2e-5, key
 
+    # (the last three: whole 128-row groups, D % 128 == 0, H % 256 == 0 -> the bf16 row-major-GEMM flow of wsae_gemm256x.hip:
+    # relu / dpre in the GEMM epilogues, no transposed copies; one of them with a partly filled last 256-row tile)
     @pytest.mark.parametrize("precision,tol,D,H,B", [("fp32", 2e-5, 96, 352, 200), ("bf16", 2e-2, 96, 352, 200),
-                                                     ("fp32", 2e-5, 384, 3072, 1000), ("bf16", 2e-2, 384, 3072, 1000)])
+                                                     ("fp32", 2e-5, 384, 3072, 1000), ("bf16", 2e-2, 384, 3072, 1000),
+                                                     ("bf16", 2e-2, 384, 3072, 1024), ("bf16", 2e-2, 256, 1024, 640),
+                                                     ("bf16", 2e-2, 128, 512, 256)])
     def test_ragged_shapes_against_the_oracle(self, device, precision, tol, D, H, B):
         """Batches and widths that are not multiples of the 64/128/256 tiles; the larger shape takes the persistent
         LDS-DMA GEMM (split-K for the two weight-gradient contractions), the smaller one the simple 128 x 128 kernel."""
@@ -497,17 +501,30 @@ class TestDdpClock:
         fired_other = torch.from_numpy(((other["hidden"] > 0).any(axis=0)).astype(np.float32)).to(device)
         seen = {}
 
-        def fake_all_reduce(flat, exchange_dtype=torch.float32, unpack=None):
-            P = flat.numel() - H
-            seen["local"] = flat[P:].clone()
-            flat[P:] += fired_other     # SUM over the two ranks
-            flat[:P] *= 2.0             # (both ranks hold this rank's gradients: sum = 2x, scale 1/2 below)
-            if unpack is not None:      # bf16 wire: the trainer widens the summed buffer itself (and takes the norm)
-                unpack(flat.to(exchange_dtype))
-            return 0.5
+        class FakeExchange:
+            """Stands in for whisper_sae.distributed.WireExchange: the views the trainer hands over are 'summed' with what a
+            second rank holding the same gradients and the other batch's fired indicators would have contributed."""
+
+            def __init__(self):
+                self.views = []
+
+            def start(self, view):
+                self.views.append(view)
+
+            def finish(self):
+                torch.cuda.synchronize()
+                for v in self.views:
+                    if v.numel() == 2:        # the metric pair (loss, l0)
+                        v *= 2.0
+                        continue
+                    P = v.numel() - H         # narrow inputs: ONE view = the whole wire [gradients | fired]
+                    seen["local"] = v[P:].clone()
+                    v[P:] += fired_other      # SUM over the two ranks
+                    v[:P] *= 2.0              # (both ranks hold this rank's gradients: sum = 2x, scale 1/2 below)
+                return 0.5
 
         monkeypatch.setattr(T, "world", lambda: (None, 2))
-        monkeypatch.setattr(T, "sync_gradients", fake_all_reduce)
+        monkeypatch.setattr(T, "WireExchange", FakeExchange)
         tr.train_step(torch.from_numpy(mine).to(device))
         torch.cuda.synchronize()
         fwd = O.forward(st, mine, "fp32", training=True)      # this rank's own stamps (step_count -> 1)

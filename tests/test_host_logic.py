@@ -140,6 +140,29 @@ class TestTrainerHostLogic:
                 tr.scheduler.step()
             assert got == c["values"], name  # same torch scheduler classes -> bit-identical
 
+    def test_lean_scheduler_step_is_torchs_step(self, golden_dir, tmp_path):
+        """``SAETrainer._scheduler_step`` (what ``train_step`` calls) against golden set G5 AND against plain ``.step()`` on a
+        twin: the rate, ``get_last_lr()`` and the whole ``state_dict()`` stay bit-equal at every step, and a run may switch
+        between the two paths at any point."""
+        cases = json.loads((golden_dir / "g5_lr_schedule.json").read_text())
+        for name, c in cases.items():
+            cfg = TrainingConfig(learning_rate=c["lr"], warmup_steps=c["warmup_cfg"], use_amp=False, num_workers=0)
+            fast = SAETrainer(TopKSAE(32, 64, k=4), cfg, device="cpu", run_dir=tmp_path / (name + "f"))
+            twin = SAETrainer(TopKSAE(32, 64, k=4), cfg, device="cpu", run_dir=tmp_path / (name + "t"))
+            fast.setup_scheduler(c["total"])
+            twin.setup_scheduler(c["total"])
+            assert fast._sched_fast
+            for i in range(len(c["values"])):
+                assert fast.optimizer.param_groups[0]["lr"] == c["values"][i], (name, i)
+                if i % 7 == 3:
+                    fast.scheduler.step()       # a plain step in the middle of lean ones
+                else:
+                    fast._scheduler_step()
+                twin.scheduler.step()
+                assert fast.optimizer.param_groups[0]["lr"] == twin.optimizer.param_groups[0]["lr"], (name, i)
+                assert fast.scheduler.get_last_lr() == twin.scheduler.get_last_lr()
+            assert fast.scheduler.state_dict() == twin.scheduler.state_dict(), name
+
     def test_optimizer_state_dict_layout(self, trainer, golden_dir):
         api = json.loads((golden_dir / "g9_api.json").read_text())
         tr, _ = trainer

@@ -108,6 +108,7 @@ struct wsae_ctx {
     int32_t* row_order;   // [maxB] rows sorted by error (resample)
     int relu_fp8;         // 1: the ReLU SAE's two forward GEMMs run on fp8 e4m3 operands (wsae_ctx_set_relu_fp8)
     void* relu_ws;        // ReLU-SAE workspace (wsae_relu.hip), allocated by wsae_ctx_reserve_relu
+    int relu_x_B;         // batch size of the last ReLU forward that ran the row-major-GEMM flow (its bf16 hidden is in relu_ws); 0 = none
     float* fired;         // caller-owned [H] indicator buffer for the DDP dead-feature clock, or null
     int n_dec_blocks;     // blocks used by the last decode launch (partials to reduce)
     int n_sq_parts;       // global-norm partials left in part_sq by the last wsae_weight_grads
@@ -263,3 +264,21 @@ bool wsae_internal_gemm256d_fp8(wsae_ctx* c, const void* A, int64_t lda, const v
                                 hipStream_t st);
 bool wsae_internal_gemm256d(wsae_ctx* c, const void* A, int64_t lda, const void* Bt, int64_t ldb, const float* bias, float* C,
                             int64_t ldc, int M, int N, int K, int nsplit, int64_t cz, hipStream_t st);
+
+// internal (wsae_gemm256x.hip): persistent bf16 GEMM with row-major-in-K operands and fused epilogues (the ReLU SAE's dense path)
+enum { GX_EPI_PLAIN = 0, GX_EPI_RELU = 1, GX_EPI_DPRE = 2 };
+struct GxEpi {
+    const float* bias;     // PLAIN / RELU: + bias[n] (nullable; z = 0 only)
+    float* c;              // PLAIN: fp32 C [M][ldc] (+ z * cz);  RELU: optional fp32 copy of hidden (nullable)
+    int64_t ldc, cz;
+    bf16_t* out16;         // RELU: hidden bf16 [M][ld16];  DPRE: dpre bf16 [M][ld16]
+    const bf16_t* mask16;  // DPRE: hidden bf16 [M][ld16]
+    int64_t ld16;
+    const float* colw;     // RELU / DPRE: per-column weights of the L1 term (nullable = 1)
+    float l1;              // DPRE: sparsity_weight / (B H)
+    float* part;           // RELU: part[tile] = sum relu * w, part[nslots + tile] = count(relu > 0)
+    int nslots;
+    float* colpart;        // DPRE: colpart[(m0 / 128 + wm)][n] = column sums of dpre over 128 rows
+};
+bool wsae_internal_gemm256x(wsae_ctx* c, int a_rm, int b_rm, int epi, const void* A, int64_t lda, const void* Bm, int64_t ldb,
+                            int M, int N, int K, int nsplit, const GxEpi& e, hipStream_t st);

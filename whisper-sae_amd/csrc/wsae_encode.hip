@@ -318,10 +318,25 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
 // 128 x 128 tiles, four waves, register-staged prefetch.  Serves the shapes the persistent kernel does not:
 // small batches, H not a multiple of 256, an odd number of K slabs.
 // ------------------------------------------------------------------------------------------------
+// A rows through a row list (the batch's rows of the activation ring, gathered by the GEMM itself): the slab_load of
+// wsae_mfma.h with row m -> arows[m]
+template <typename T>
+__device__ __forceinline__ void slab_load_rows(SlabRegs<T>& r, const T* __restrict__ base, int64_t ld, const int32_t* __restrict__ arows,
+                                               int row0, int n_rows, int k0, int k_total, int tid) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    auto chunk = [&](int c) -> uint4 {
+        const int row = row0 + (c >> 3), k = k0 + (c & 7) * EPC;
+        if (row < n_rows && k < k_total) return *(const uint4*)(base + (int64_t)arows[row] * ld + k);
+        return make_uint4(0, 0, 0, 0);
+    };
+    r.v0 = chunk(tid); r.v1 = chunk(tid + 256); r.v2 = chunk(tid + 512); r.v3 = chunk(tid + 768);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 encode_gemm_kernel(const T* __restrict__ xb, const T* __restrict__ W, const float* __restrict__ bias,
-                   float* __restrict__ pre, int ldp, int B, int H, int D) {
+                   float* __restrict__ pre, int ldp, int B, int H, int D, const int32_t* __restrict__ arows,
+                   int64_t* __restrict__ step_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
     char* Bs = smem + TILE_LDS_BYTES;
@@ -329,6 +344,8 @@ encode_gemm_kernel(const T* __restrict__ xb, const T* __restrict__ W, const floa
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * TILE_M, n0 = blockIdx.x * TILE_N;
     constexpr int KT = Mfma<T>::KT;
+    // (when it gathers the batch rows itself this is the first kernel of the step: it advances the clock of model.py:175)
+    if (step_count && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *step_count += 1;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -339,7 +356,8 @@ encode_gemm_kernel(const T* __restrict__ xb, const T* __restrict__ W, const floa
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     SlabRegs<T> ra, rb;
-    slab_load<T>(ra, xb, D, m0, B, 0, D, tid);
+    if (arows) slab_load_rows<T>(ra, xb, D, arows, m0, B, 0, D, tid);
+    else slab_load<T>(ra, xb, D, m0, B, 0, D, tid);
     slab_load<T>(rb, W, D, n0, H, 0, D, tid);
     const int nk = (D + KT - 1) / KT;
     for (int kt = 0; kt < nk; ++kt) {
@@ -347,7 +365,8 @@ encode_gemm_kernel(const T* __restrict__ xb, const T* __restrict__ W, const floa
         slab_store<T>(rb, Bs, tid);
         __syncthreads();
         if (kt + 1 < nk) {
-            slab_load<T>(ra, xb, D, m0, B, (kt + 1) * KT, D, tid);
+            if (arows) slab_load_rows<T>(ra, xb, D, arows, m0, B, (kt + 1) * KT, D, tid);
+            else slab_load<T>(ra, xb, D, m0, B, (kt + 1) * KT, D, tid);
             slab_load<T>(rb, W, D, n0, H, (kt + 1) * KT, D, tid);
         }
         Mfma<T>::slab(As, Bs, wm * 64, wn * 64, lane, acc);
@@ -367,6 +386,51 @@ encode_gemm_kernel(const T* __restrict__ xb, const T* __restrict__ W, const floa
                 if (b < B) pre[(int64_t)b * ldp + h] = acc[mi][ni][r] + bv;
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode_direct_kernel (bf16, small batches - the reference YAMLs' own 64 / 128 rows): no LDS, no barrier.  A wave owns one
+// 32 x 32 tile of pre (32 batch rows x 32 features); both MFMA operands are K-contiguous in memory, so every fragment is one
+// 16-byte global load per lane - the x rows through the step's row list, the W_e rows from L2 - issued 8 K steps at a time.
+// Grid (H / 32, ceil(B / 128)): 96 workgroups at 384 -> 3072 / B = 128, where the 128 x 128 LDS kernel has 24.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+encode_direct_kernel(const bf16_t* __restrict__ xa, const int32_t* __restrict__ arows, const bf16_t* __restrict__ W,
+                     const float* __restrict__ bias, float* __restrict__ pre, int ldp, int B, int H, int D,
+                     int64_t* __restrict__ step_count) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (step_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *step_count += 1;  // model.py:175
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 128 + wave * 32;
+    if (m0 >= B) return;
+    const int r = lane & 31, h = lane >> 5;
+    const int mrow = min(m0 + r, B - 1);  // rows past the batch repeat its last row: never stored
+    const int64_t arow = arows ? (int64_t)arows[mrow] : (int64_t)mrow;
+    const bf16_t* ap = xa + arow * D + 8 * h;
+    const bf16_t* bp = W + (int64_t)min(n0 + r, H - 1) * D + 8 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nk = D / 16;
+    for (int k0 = 0; k0 < nk; k0 += 8) {
+        bf16x8 a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = min(k0 + j, nk - 1);  // (clamped: unconditional loads; the surplus steps are not multiplied)
+            a[j] = *(const bf16x8*)(ap + 16 * kk);
+            b[j] = *(const bf16x8*)(bp + 16 * kk);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < nk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[j], acc, 0, 0, 0);
+    }
+    const int n = n0 + r;
+    if (n >= H) return;
+    const float bv = bias[n];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (m < B) pre[(int64_t)m * ldp + n] = acc[i] + bv;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -547,10 +611,14 @@ static int gemm_dense(wsae_ctx* c, const float* params, int B, float* pre, int l
         encode_gemm256d_kernel<T><<<min(ntiles, c->cus), 512, G256D_LDS, st>>>(xa, c->D, W, c->D, bias, pre, ldp, B, H, c->D, ntn,
                                                                               ntiles, 1, 0, smax, arows, step_count);
         if (pre == c->pre) c->smax_valid = smax ? 1 : 0;
+    } else if (sizeof(T) == 2 && B <= 1024 && c->D % 16 == 0) {
+        if (pre == c->pre) c->smax_valid = 0;
+        encode_direct_kernel<<<dim3(ceil_div(H, 32), ceil_div(B, 128)), 256, 0, st>>>((const bf16_t*)xa, arows, (const bf16_t*)W, bias, pre,
+                                                                                     ldp, B, H, c->D, step_count);
     } else {
         if (pre == c->pre) c->smax_valid = 0;
         dim3 gg(ceil_div(H, TILE_N), ceil_div(B, TILE_M));
-        encode_gemm_kernel<T><<<gg, 256, 2 * TILE_LDS_BYTES, st>>>(xa, W, bias, pre, ldp, B, H, c->D);
+        encode_gemm_kernel<T><<<gg, 256, 2 * TILE_LDS_BYTES, st>>>(xa, W, bias, pre, ldp, B, H, c->D, arows, step_count);
     }
     WSAE_PROF_END(c, WSAE_K_ENCODE_GEMM, st);
     WSAE_LAUNCH_CHECK();
@@ -563,7 +631,9 @@ static int gemm_dense(wsae_ctx* c, const float* params, int B, float* pre, int l
 template <typename T>
 static int stage_and_gemm(wsae_ctx* c, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,
                           float* pre, int64_t* step_count, int direct, hipStream_t st) {
-    if (direct && sizeof(T) == 2 && x_dtype == WSAE_DT_BF16 && persistent_ok<T>(c, B)) {
+    // (the persistent kernel for large batches; below its minimum the 128 x 128 kernel takes the row list the same way: at the
+    // reference's own batch sizes the staging launch was 5 of the step's ~80 us of kernels)
+    if (direct && sizeof(T) == 2 && x_dtype == WSAE_DT_BF16) {
         c->xT_valid = 0;
         return gemm_dense<T>(c, params, B, pre, c->H, (const T*)x, rows, step_count, st);
     }

@@ -1,0 +1,247 @@
+// Persistent 256 x 256 bf16 GEMM with operand-layout and epilogue variants (the ReLU SAE's dense path, wsae_relu.hip;
+// reference ReLUSAE, model.py:260-322).
+//
+//   C[M][N] (+ z * cz) = A . B over K range z, fp32 accumulate, where each operand is given either
+//     K-contiguous ("NT": A[m][k], Bt[n][k] - one ds_read_b128 per MFMA fragment), or
+//     ROW-MAJOR IN K ("RM": Ak[k][m], Bk[k][n] - the layout activations and their gradients already have in memory),
+//       staged as [column block of 64][64 k rows][128 bytes] by LDS-DMA and read with ds_read_b64_tr_b16 (two per
+//       fragment; conflict-free under rm_swz) - so no kernel has to write a transposed copy of a [B, H] matrix.
+//   The five GEMMs of a ReLU-SAE step then read x, hidden, g, dpre and the decoder shadow exactly as they lie:
+//     hidden = relu(x W_e^T + b_e)      NT/NT, epilogue RELU : bf16 hidden (+ the fp32 API copy on request), L1 / l0 partials
+//     recon  = hidden W_d^T             NT/RM (W_dT [H][D] is W_d row-major in K = h), split-K 2 into two slabs
+//     dh     = g W_d -> dpre            NT/NT, epilogue DPRE : dpre = (dh + l1 w) * [hidden > 0] as bf16, db_e column partials
+//     dW_e   = dpre^T x, dW_dT = hidden^T g      RM/RM, split-K over the batch into the slabs
+//   Same skeleton as encode_gemm256d_kernel (wsae_encode.hip): one workgroup of 8 waves per CU walks its tiles, two 64 KB
+//   LDS stages filled by LDS-DMA a K slab ahead (the next tile's first slab lands while the current tile is stored), wave
+//   tile 128 x 64 = 4 x 2 MFMA tiles of 32x32x16, the epilogue goes through per-wave LDS patches so that every lane owns 4
+//   consecutive columns of a row.  bf16 only.
+#include "wsae_common.h"
+#include "wsae_mfma.h"
+
+#define GX_STAGE (2 * 256 * SWZ_ROW_BYTES)  // A tile + B tile = 64 KB
+#define GX_STAGE1 (72 * 1024)
+#define GX_LDS (GX_STAGE1 + GX_STAGE)       // 136 KB
+
+__device__ __forceinline__ int gx_rm_swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+typedef __attribute__((address_space(3))) bf16x4 gx_lds_bf16x4;
+
+template <bool ARM, bool BRM, int EPI>
+__global__ void __launch_bounds__(512)
+gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm, int64_t ldb, int M, int N, int Kr,
+                int ntn, int ntiles_mn, int nsplit, GxEpi e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 64, EPC = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = Kr / KT;
+    const int col = lane & 31, rq = lane >> 5;
+    constexpr int PS = 68;
+    float* patch = (float*)smem + wave * 32 * PS;  // inside stage 0's region
+    const int pr = lane >> 4, pc = (lane & 15) * 4;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int dma_r = lane >> 3, dma_s = lane & 7;
+    const int ntiles = ntiles_mn * nsplit;
+
+    // K slab k0 of tile (m0, n0) into stage st: pieces 0..31 = the A operand, 32..63 = the B operand
+    auto dma = [&](int m0, int n0, int64_t k0, int st) {
+        const uint32_t base = smem_lds + (st ? GX_STAGE1 : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int piece = wave + 8 * j;  // 0..63
+            const int pi = piece & 31;
+            const bool isA = j < 4;
+            const bf16_t* src;
+            if (isA ? ARM : BRM) {
+                const int krow = (pi & 7) * 8 + dma_r;                 // k row inside the slab
+                const int cbk = (pi >> 3) * 64 + (dma_s ^ gx_rm_swz(krow)) * EPC;  // column inside the 256-wide tile
+                if (isA) src = A + (k0 + krow) * lda + min(m0 + cbk, M - EPC);
+                else src = Bm + (k0 + krow) * ldb + min(n0 + cbk, N - EPC);
+            } else {
+                const int row = pi * 8 + dma_r;                        // operand row inside the 256-row tile
+                const int c = dma_s ^ ((row >> 1) & 7);
+                if (isA) src = A + (int64_t)min(m0 + row, M - 1) * lda + k0 + c * EPC;
+                else src = Bm + (int64_t)min(n0 + row, N - 1) * ldb + k0 + c * EPC;
+            }
+            glds16(src, base + piece * 1024);
+        }
+    };
+    auto m_of = [&](int t) { return ((t % ntiles_mn) / ntn) * 256; };
+    auto n_of = [&](int t) { return ((t % ntiles_mn) % ntn) * 256; };
+    auto k_of = [&](int t) { return (int64_t)(t / ntiles_mn) * Kr; };
+
+    // lane-constant fragment addresses (offsets inside an operand's 32 KB image)
+    const int r31 = lane & 31, h = lane >> 5;
+    const int sw = (r31 >> 1) & 7;
+    int a_nt = (wm * 128 + r31) * SWZ_ROW_BYTES, b_nt = (wn * 64 + r31) * SWZ_ROW_BYTES;
+    int a_rm[4][2], b_rm[2][2];
+    {
+        const int l15 = lane & 15, g1 = (lane >> 4) & 1;
+        auto rm_addr = [&](int col0, int q2) {
+            const int c0 = col0 + g1 * 16 + 4 * (l15 & 3);
+            const int row = 8 * h + 4 * q2 + (l15 >> 2);  // + 16 kk: does not change the swizzle
+            return (c0 >> 6) * 8192 + row * 128 + ((((c0 & 63) >> 3) ^ gx_rm_swz(row)) << 4) + 8 * (l15 & 1);
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) a_rm[i][q2] = rm_addr(wm * 128 + 32 * i, q2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) b_rm[i][q2] = rm_addr(wn * 64 + 32 * i, q2);
+    }
+    auto rm_frag = [&](const char* img, const int (&ad)[2], int kk) -> bf16x8 {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((gx_lds_bf16x4*)(img + ad[0] + kk * 2048));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((gx_lds_bf16x4*)(img + ad[1] + kk * 2048));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    int it = 0, st = 1;
+    int tile = (int)blockIdx.x;
+    if (tile < ntiles) dma(m_of(tile), n_of(tile), k_of(tile), st);
+    for (; tile < ntiles; tile = (int)blockIdx.x + (++it) * (int)gridDim.x) {
+        const int m0 = m_of(tile), n0 = n_of(tile);
+        const int64_t kbase = k_of(tile);
+        const int z = tile / ntiles_mn;
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int nt = min(tile + (int)gridDim.x, ntiles - 1);
+        for (int kt = 0; kt < nk; ++kt) {
+            dma_wait();       // slab kt (issued one step ago) has landed
+            __syncthreads();  // ... for every wave; and everybody is done reading the other stage
+            if (kt + 1 < nk) dma(m0, n0, kbase + (int64_t)(kt + 1) * KT, st ^ 1);
+            else dma(m_of(nt), n_of(nt), k_of(nt), st ^ 1);
+            const char* As = smem + (st ? GX_STAGE1 : 0);
+            const char* Bs = As + 256 * SWZ_ROW_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((kk * 2 + h) ^ sw) << 4;
+                bf16x8 a[4], b[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (ARM) a[i] = rm_frag(As, a_rm[i], kk);
+                    else a[i] = *(const bf16x8*)(As + a_nt + i * 32 * SWZ_ROW_BYTES + co);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if constexpr (BRM) b[i] = rm_frag(Bs, b_rm[i], kk);
+                    else b[i] = *(const bf16x8*)(Bs + b_nt + i * 32 * SWZ_ROW_BYTES + co);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+            st ^= 1;
+        }
+        // the slab in flight targets stage 1 (st == 1 again: nk is even); the patches take stage 0's place
+        __syncthreads();
+        const int ncol = n0 + wn * 64 + pc;  // this lane's 4 columns
+        const bool col_ok = ncol < N;        // (N is a multiple of 4)
+        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (EPI != GX_EPI_DPRE && e.bias && z == 0 && col_ok) bv4 = *(const float4*)(e.bias + ncol);
+        if (EPI != GX_EPI_PLAIN && e.colw && col_ok) w4 = *(const float4*)(e.colw + ncol);
+        float s_l1 = 0.f, s_cnt = 0.f;                 // RELU partials
+        float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);  // DPRE column sums (this lane's rows)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * rq) * PS + ni * 32 + col] = acc[mi][ni][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rl = pr + 4 * i;
+                const int m = m0 + wm * 128 + mi * 32 + rl;
+                float4 v = *(const float4*)(patch + rl * PS + pc);
+                const bool ok = m < M && col_ok;
+                if constexpr (EPI == GX_EPI_PLAIN) {
+                    v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+                    if (ok) *(float4*)(e.c + (int64_t)z * e.cz + (int64_t)m * e.ldc + ncol) = v;
+                } else if constexpr (EPI == GX_EPI_RELU) {
+                    v.x = fmaxf(v.x + bv4.x, 0.f); v.y = fmaxf(v.y + bv4.y, 0.f);
+                    v.z = fmaxf(v.z + bv4.z, 0.f); v.w = fmaxf(v.w + bv4.w, 0.f);
+                    if (ok) {
+                        bf16x4 o;
+                        o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+                        *(bf16x4*)(e.out16 + (int64_t)m * e.ld16 + ncol) = o;
+                        if (e.c) *(float4*)(e.c + (int64_t)m * e.ldc + ncol) = v;
+                        s_l1 += (v.x * w4.x + v.y * w4.y) + (v.z * w4.z + v.w * w4.w);
+                        s_cnt += (float)((v.x > 0.f) + (v.y > 0.f) + (v.z > 0.f) + (v.w > 0.f));
+                    }
+                } else {
+                    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) {
+                        const bf16x4 hm = *(const bf16x4*)(e.mask16 + (int64_t)m * e.ld16 + ncol);
+                        d.x = (float)hm[0] > 0.f ? v.x + e.l1 * w4.x : 0.f;
+                        d.y = (float)hm[1] > 0.f ? v.y + e.l1 * w4.y : 0.f;
+                        d.z = (float)hm[2] > 0.f ? v.z + e.l1 * w4.z : 0.f;
+                        d.w = (float)hm[3] > 0.f ? v.w + e.l1 * w4.w : 0.f;
+                        bf16x4 o;
+                        o[0] = (bf16_t)d.x; o[1] = (bf16_t)d.y; o[2] = (bf16_t)d.z; o[3] = (bf16_t)d.w;
+                        *(bf16x4*)(e.out16 + (int64_t)m * e.ld16 + ncol) = o;
+                    }
+                    csum.x += d.x; csum.y += d.y; csum.z += d.z; csum.w += d.w;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (EPI == GX_EPI_RELU) {
+            // tile partials in fixed order: wave sums -> LDS -> thread 0 (the patches are free: every wave passed its last wave barrier
+            // only for ITS OWN patch, so the scratch below lives behind the patches)
+            float* red = (float*)smem + 8 * 32 * PS;  // 16 floats behind the eight patches (inside stage 0: 69.6 KB < 72 KB)
+            const float a = wave_sum(s_l1), c = wave_sum(s_cnt);
+            if (lane == 0) { red[wave] = a; red[8 + wave] = c; }
+            __syncthreads();
+            if (tid == 0) {
+                float ta = 0.f, tc = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { ta += red[w]; tc += red[8 + w]; }
+                e.part[tile] = ta;
+                e.part[e.nslots + tile] = tc;
+            }
+        }
+        if constexpr (EPI == GX_EPI_DPRE) {
+            // lanes pc, pc + 16, pc + 32, pc + 48 hold the four row classes of the same 4 columns
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+                csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+            }
+            if (lane < 16 && col_ok && m0 + wm * 128 < M) *(float4*)(e.colpart + (int64_t)(m0 / 128 + wm) * N + ncol) = csum;
+        }
+        // (the loop top's barrier separates these patch reads from the next slab landing in stage 0)
+    }
+    dma_wait();
+}
+
+// host side --------------------------------------------------------------------------------------------------------------
+// Shape rules: M, N multiples of 8 (N of 4 for fp32 C), Kr = K / nsplit a multiple of 128 (an even number of 64-deep slabs),
+// leading dimensions multiples of 8 elements.  Returns false when the shape does not qualify (the caller keeps its old path).
+bool wsae_internal_gemm256x(wsae_ctx* c, int a_rm, int b_rm, int epi, const void* A, int64_t lda, const void* Bm, int64_t ldb,
+                            int M, int N, int K, int nsplit, const GxEpi& e, hipStream_t st) {
+    if (M < 256 || N < 128 || M % 8 || N % 8 || nsplit < 1 || K % nsplit || (K / nsplit) % 128 || lda % 8 || ldb % 8) return false;
+    if (epi != GX_EPI_PLAIN && nsplit != 1) return false;
+    const int ntn = ceil_div(N, 256), ntiles_mn = ntn * ceil_div(M, 256);
+    if (epi == GX_EPI_RELU && ntiles_mn > e.nslots) return false;
+    const int grid = min(ntiles_mn * nsplit, c->cus);
+    const bf16_t* a = (const bf16_t*)A;
+    const bf16_t* b = (const bf16_t*)Bm;
+#define GX_LAUNCH(AR, BR, EP) gemm256x_kernel<AR, BR, EP><<<grid, 512, GX_LDS, st>>>(a, lda, b, ldb, M, N, K / nsplit, ntn, ntiles_mn, nsplit, e)
+    if (!a_rm && !b_rm && epi == GX_EPI_RELU) GX_LAUNCH(false, false, GX_EPI_RELU);
+    else if (!a_rm && !b_rm && epi == GX_EPI_DPRE) GX_LAUNCH(false, false, GX_EPI_DPRE);
+    else if (!a_rm && b_rm && epi == GX_EPI_PLAIN) GX_LAUNCH(false, true, GX_EPI_PLAIN);
+    else if (a_rm && b_rm && epi == GX_EPI_PLAIN) GX_LAUNCH(true, true, GX_EPI_PLAIN);
+    else return false;
+#undef GX_LAUNCH
+    return true;
+}

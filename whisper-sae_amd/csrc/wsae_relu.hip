@@ -259,11 +259,13 @@ relu_act_kernel(const float* __restrict__ pre, float* __restrict__ hidden, T* __
 }
 
 // ---- residual: loss partials; in backward also g (contraction dtype, row-major into xb), gT, db_d partials ----
+// recon2 / recon_out (forward of the row-major-GEMM flow): the reconstruction arrives as two split-K slabs, their sum is
+// written to recon_out on the way
 template <typename T, int XDT, bool BWD>
 __global__ void __launch_bounds__(256)
 resid_kernel(const float* __restrict__ recon, const void* __restrict__ x, const int32_t* __restrict__ rows, int B, int D,
              int ldT, float scale, T* __restrict__ g_rm, T* __restrict__ gT, float* __restrict__ part_dbd,
-             float* __restrict__ part_loss) {
+             float* __restrict__ part_loss, const float* __restrict__ recon2 = nullptr, float* __restrict__ recon_out = nullptr) {
     __shared__ float tile[64][65];
     __shared__ float red[8];
     const int d0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
@@ -275,7 +277,12 @@ resid_kernel(const float* __restrict__ recon, const void* __restrict__ x, const 
         float r[4] = {0.f, 0.f, 0.f, 0.f};
         if (b < B && d < D) {
             const int64_t src = rows ? (int64_t)rows[b] : (int64_t)b;
-            const float4 rc = *(const float4*)(recon + (int64_t)b * D + d);
+            float4 rc = *(const float4*)(recon + (int64_t)b * D + d);
+            if (recon2) {
+                const float4 r2 = *(const float4*)(recon2 + (int64_t)b * D + d);
+                rc.x += r2.x; rc.y += r2.y; rc.z += r2.z; rc.w += r2.w;
+            }
+            if (recon_out) *(float4*)(recon_out + (int64_t)b * D + d) = rc;
             r[0] = rc.x - load_act<XDT>(x, src * D + d);
             r[1] = rc.y - load_act<XDT>(x, src * D + d + 1);
             r[2] = rc.z - load_act<XDT>(x, src * D + d + 2);
@@ -293,7 +300,7 @@ resid_kernel(const float* __restrict__ recon, const void* __restrict__ x, const 
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int dl = r16 + 16 * p, d = d0 + dl, b = b0 + 4 * q;
-            if (d < D && b < ldT)
+            if (gT && d < D && b < ldT)
                 store4<T>(gT + (int64_t)d * ldT + b, tile[4 * q][dl], tile[4 * q + 1][dl], tile[4 * q + 2][dl], tile[4 * q + 3][dl]);
         }
         if (threadIdx.x < 64 && d0 + (int)threadIdx.x < D) {  // column sums of this tile's 64 rows, fixed order
@@ -458,6 +465,97 @@ static void quant_rows(hipStream_t st, const void* src, int dtype, const int32_t
     else quant_rows_kernel<WSAE_DT_BF16><<<ceil_div(R, 4), 256, 0, st>>>(src, rows, R, C, q, scale);
 }
 
+// ---- the row-major-GEMM flow (bf16, wsae_gemm256x.hip): no transposed copies, relu / dpre fused into the GEMM epilogues ----
+// Eligible shapes: whole 128-row groups of batch rows, D a multiple of 128, H a multiple of 256.  Then per step the dense
+// [B, H] traffic is: bf16 hidden out (1x), in (3x: decoder GEMM, dpre epilogue, dW_d contraction), bf16 dpre out + in - against
+// fp32 pre, fp32 hidden, fp32 dh and two transposed bf16 copies out and back in on the general path below (1.2 GB at
+// 384 -> 3072 / B = 16384).
+bool x_flow_ok(const wsae_ctx* c, int B) {
+    return c->prec == WSAE_PREC_BF16 && !c->relu_fp8 && B >= 256 && B % 128 == 0 && c->D % 128 == 0 && c->H % 256 == 0 && 2 * c->D <= c->H;
+}
+
+int x_split(int B) {  // split-K over the batch: ranges of whole 128-row groups, at least 512 rows each
+    int nz = WSAE_WGRAD_MAX_SPLIT;
+    while (nz > 1 && (B % nz || (B / nz) % 128 || B / nz < 512)) nz >>= 1;
+    return nz;
+}
+
+int forward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, float weight,
+              float* hidden, float* recon, wsae_stats* stats, float* sparsity_out, hipStream_t st) {
+    const int D = ctx->D, H = ctx->H;
+    const int ldT = (B + 127) / 128 * 128;
+    const ReluWs ws = host_ws(ctx);
+    int rc = wsae_internal_stage(ctx, params, x, x_dtype, rows, B, st);  // xb = bf16(x) [B][D] (the contractions read it row-major)
+    if (rc) return rc;
+    GxEpi e1 = {};
+    e1.bias = params + ctx->off[2];
+    e1.c = hidden; e1.ldc = H;
+    e1.out16 = (bf16_t*)ws.hid; e1.ld16 = H;
+    e1.colw = ctx->relu_l1w;
+    e1.part = ws.part; e1.nslots = ws.nblk;
+    WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 0, GX_EPI_RELU, ctx->xb, D, ctx->We_bf16, D, B, H, D, 1, e1, st),
+                 "wsae_relu_forward: encoder GEMM rejected B %d, D %d, H %d", B, D, H);
+    GxEpi e2 = {};
+    e2.bias = params + ctx->off[3];
+    e2.c = ctx->pre; e2.ldc = D; e2.cz = (int64_t)B * D;  // two split-K slabs in the (otherwise unused) pre-activation scratch
+    WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 1, GX_EPI_PLAIN, ws.hid, H, ctx->WdT_bf16, D, B, D, H, 2, e2, st),
+                 "wsae_relu_forward: decoder GEMM rejected B %d, D %d, H %d", B, D, H);
+    dim3 gr(ceil_div(D, 64), ceil_div(ldT, 64));
+    if (x_dtype == WSAE_DT_F32)
+        resid_kernel<bf16_t, WSAE_DT_F32, false><<<gr, 256, 0, st>>>(ctx->pre, x, rows, B, D, ldT, 0.f, nullptr, nullptr, nullptr,
+                                                                    ws.part + 2 * ws.nblk, ctx->pre + (int64_t)B * D, recon);
+    else
+        resid_kernel<bf16_t, WSAE_DT_BF16, false><<<gr, 256, 0, st>>>(ctx->pre, x, rows, B, D, ldT, 0.f, nullptr, nullptr, nullptr,
+                                                                     ws.part + 2 * ws.nblk, ctx->pre + (int64_t)B * D, recon);
+    const int nt1 = ceil_div(H, 256) * ceil_div(B, 256);
+    relu_fwd_finish_kernel<<<1, 256, 0, st>>>(ws.part, nt1, (int)(gr.x * gr.y), ws.nblk, B, ctx->loss_cols, H, weight, stats,
+                                              sparsity_out, ws.scal);
+    WSAE_LAUNCH_CHECK();
+    ctx->relu_x_B = B;
+    return WSAE_OK;
+}
+
+int backward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, float weight,
+               const float* recon, float* grads, hipStream_t st) {
+    const int D = ctx->D, H = ctx->H;
+    const int ldT = (B + 127) / 128 * 128;
+    const ReluWs ws = host_ws(ctx);
+    const float scale = 2.0f / ((float)B * (float)ctx->loss_cols);
+    dim3 gr(ceil_div(D, 64), ceil_div(ldT, 64));
+    // g = 2 (recon - x) / (B cols) as bf16 [B][D] (row-major: what both consumers read), db_d partials
+    if (x_dtype == WSAE_DT_F32)
+        resid_kernel<bf16_t, WSAE_DT_F32, true><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, scale, ctx->gb, nullptr, ctx->part_dbd,
+                                                                   ws.part + 2 * ws.nblk);
+    else
+        resid_kernel<bf16_t, WSAE_DT_BF16, true><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, scale, ctx->gb, nullptr, ctx->part_dbd,
+                                                                    ws.part + 2 * ws.nblk);
+    bf16_t* dpre = (bf16_t*)ws.hidT;  // [B][H] (the transposed-hidden buffer of the general path is free in this flow)
+    GxEpi e3 = {};
+    e3.out16 = dpre; e3.mask16 = (const bf16_t*)ws.hid; e3.ld16 = H;
+    e3.colw = ctx->relu_l1w;
+    e3.l1 = weight / ((float)B * (float)H);
+    e3.colpart = ws.colpart;
+    WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 0, GX_EPI_DPRE, ctx->gb, D, ctx->WdT_bf16, D, B, H, D, 1, e3, st),
+                 "wsae_relu_backward: dh GEMM rejected B %d, D %d, H %d", B, D, H);
+    const int nz = x_split(B);
+    const int64_t hd = (int64_t)H * D, slab_stride = 2 * hd;
+    GxEpi e4 = {};
+    e4.c = ctx->wg_slabs; e4.ldc = D; e4.cz = slab_stride;
+    WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 1, 1, GX_EPI_PLAIN, dpre, H, ctx->xb, D, H, D, B, nz, e4, st),
+                 "wsae_relu_backward: dW_e contraction rejected B %d (split %d)", B, nz);
+    GxEpi e5 = e4;
+    e5.c = ctx->wg_slabs + hd;
+    WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 1, 1, GX_EPI_PLAIN, ws.hid, H, ctx->gb, D, H, D, B, nz, e5, st),
+                 "wsae_relu_backward: dW_d contraction rejected B %d (split %d)", B, nz);
+    slab_sum_kernel<<<512, 256, 0, st>>>(ctx->wg_slabs, slab_stride, nz, slab_stride / 4, grads, grads + ctx->off[4], D);
+    colsum_kernel<<<ceil_div(H, 256), 256, 0, st>>>(ws.colpart, B / 128, H, grads + ctx->off[2]);
+    colsum_kernel<<<ceil_div(D, 256), 256, 0, st>>>(ctx->part_dbd, ceil_div(B, 64), D, grads + ctx->off[3]);
+    WSAE_LAUNCH_CHECK();
+    ctx->n_sq_parts = 0;
+    ctx->g_is_bf16 = 1;
+    return WSAE_OK;
+}
+
 template <typename T>
 int forward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, float weight,
               float* hidden, float* recon, wsae_stats* stats, float* sparsity_out, hipStream_t st) {
@@ -559,15 +657,20 @@ extern "C" int wsae_ctx_set_relu_l1_weights(wsae_ctx* ctx, const float* weights)
     return WSAE_OK;
 }
 
+extern "C" int wsae_relu_needs_hidden(const wsae_ctx* ctx, int32_t B) { return (ctx && x_flow_ok(ctx, B)) ? 0 : 1; }
+
 extern "C" int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,
                                  int32_t B, float sparsity_weight, float* hidden, float* recon, wsae_stats* stats,
                                  float* sparsity_loss_out, void* stream) {
-    WSAE_REQUIRE(ctx && params && x && hidden && recon, "wsae_relu_forward: null argument");
+    WSAE_REQUIRE(ctx && params && x && recon, "wsae_relu_forward: null argument");
     WSAE_REQUIRE(x_dtype == WSAE_DT_F32 || x_dtype == WSAE_DT_BF16, "wsae_relu_forward: unknown activation dtype %d", x_dtype);
     int rc = check_dims(ctx, B, "wsae_relu_forward");
     if (rc) return rc;
     WSAE_REQUIRE(ctx->relu_ws, "wsae_relu_forward: call wsae_ctx_reserve_relu(ctx) once after wsae_ctx_create");
     hipStream_t st = (hipStream_t)stream;
+    ctx->relu_x_B = 0;
+    if (x_flow_ok(ctx, B)) return forward_x(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, stats, sparsity_loss_out, st);
+    WSAE_REQUIRE(hidden, "wsae_relu_forward: this shape needs the fp32 hidden buffer (only the row-major-GEMM flow runs without it)");
     return ctx->prec == WSAE_PREC_BF16
                ? forward_t<bf16_t>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, stats, sparsity_loss_out, st)
                : forward_t<float>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, stats, sparsity_loss_out, st);
@@ -576,12 +679,15 @@ extern "C" int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void*
 extern "C" int wsae_relu_backward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,
                                   int32_t B, float sparsity_weight, const float* hidden, const float* recon, float* grads,
                                   void* stream) {
-    WSAE_REQUIRE(ctx && params && x && hidden && recon && grads, "wsae_relu_backward: null argument");
+    WSAE_REQUIRE(ctx && params && x && recon && grads, "wsae_relu_backward: null argument");
     WSAE_REQUIRE(x_dtype == WSAE_DT_F32 || x_dtype == WSAE_DT_BF16, "wsae_relu_backward: unknown activation dtype %d", x_dtype);
     int rc = check_dims(ctx, B, "wsae_relu_backward");
     if (rc) return rc;
     WSAE_REQUIRE(ctx->relu_ws, "wsae_relu_backward: no preceding wsae_relu_forward on this ctx");
     hipStream_t st = (hipStream_t)stream;
+    // (the forward of this batch ran the row-major-GEMM flow: its bf16 hidden is still in the workspace)
+    if (ctx->relu_x_B == B && x_flow_ok(ctx, B)) return backward_x(ctx, params, x, x_dtype, rows, B, sparsity_weight, recon, grads, st);
+    WSAE_REQUIRE(hidden, "wsae_relu_backward: the fp32 hidden of the forward is needed on this path");
     return ctx->prec == WSAE_PREC_BF16
                ? backward_t<bf16_t>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, grads, st)
                : backward_t<float>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, grads, st);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "wsae_profile_enable": (C.c_int, [_p, _i32, _i32]),
     "wsae_profile_disable": (C.c_int, [_p]),
     "wsae_profile_read": (C.c_int, [_p, _i32, C.POINTER(_i32), C.POINTER(C.c_double)]),
+    "wsae_relu_needs_hidden": (C.c_int, [_p, _i32]),
     "wsae_relu_forward": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _f32, _p, _p, _p, _p, _p]),
     "wsae_relu_backward": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _f32, _p, _p, _p, _p]),
 }

@@ -26,11 +26,15 @@ from __future__ import annotations
 import torch
 
 
+import torch.distributed as _dist
+
+
 def world():
     """``(dist_module, world_size)``; ``(None, 1)`` when not running under torch.distributed."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist, dist.get_world_size()
+    if _dist.is_available() and _dist.is_initialized():
+        n = _dist.get_world_size()
+        if n > 1:
+            return _dist, n
     return None, 1
 
 

@@ -122,12 +122,15 @@ class SAEEngine:
             self._work[batch] = w
         return w
 
-    def relu_work(self, batch: int) -> dict:
+    def relu_work(self, batch: int, handle: int = 0) -> dict:
+        """Scratch of one ReLU step.  ``hidden`` (dense fp32 [B, H]) is only allocated when the kernels need it
+        (``wsae_relu_needs_hidden``: the bf16 row-major-GEMM flow keeps the code as bf16 in the ctx workspace)."""
         w = self._work.get(("relu", batch))
         if w is None:
             if len(self._work) > 4:
                 self._work.clear()
-            w = {"hidden": torch.empty(batch, self.H, dtype=torch.float32, device=self.device),
+            need = True if not handle else bool(self.lib.wsae_relu_needs_hidden(handle, batch))
+            w = {"hidden": torch.empty(batch, self.H, dtype=torch.float32, device=self.device) if need else None,
                  "recon": torch.empty(batch, self.D, dtype=torch.float32, device=self.device)}
             self._work[("relu", batch)] = w
         return w

@@ -166,6 +166,7 @@ class TopKSAE(nn.Module):
         self.register_buffer("feature_last_activated", torch.zeros(hidden_dim, dtype=torch.long))
         self.register_buffer("step_count", torch.tensor(0, dtype=torch.long))
         self._engine: Optional[SAEEngine] = None
+        self._bound_ptrs = None
         self._last_code = None
 
     # -- device binding --------------------------------------------------------------------------
@@ -181,6 +182,13 @@ class TopKSAE(nn.Module):
         if self.k > self.hidden_dim:
             raise ValueError(f"k={self.k} exceeds hidden_dim={self.hidden_dim}")
         eng = self._engine
+        if eng is not None and eng.device == dev and eng.k == self.k:
+            # fast path (every train step comes through here twice): nothing was re-pointed since the last full check
+            ptrs = (self.encoder.weight.data_ptr(), self.decoder.weight.data_ptr(), self.encoder.bias.data_ptr(),
+                    self.decoder.bias.data_ptr(), self.b_pre.data_ptr(), self.feature_last_activated.data_ptr(),
+                    self.step_count.data_ptr())
+            if ptrs == self._bound_ptrs:
+                return eng
         if eng is None or eng.device != dev or eng.k != self.k:
             if eng is not None:
                 eng.close()
@@ -196,6 +204,10 @@ class TopKSAE(nn.Module):
         for buf in (self.feature_last_activated, self.step_count):
             if buf.device != dev:
                 raise N.WsaeError("module buffers and parameters are on different devices; use module.to(device)")
+        # (the views are slices of the engine's pack: equal pointers = same device, shape and stride as checked above)
+        self._bound_ptrs = (self.encoder.weight.data_ptr(), self.decoder.weight.data_ptr(), self.encoder.bias.data_ptr(),
+                            self.decoder.bias.data_ptr(), self.b_pre.data_ptr(), self.feature_last_activated.data_ptr(),
+                            self.step_count.data_ptr())
         return eng
 
     def param_token(self) -> tuple:

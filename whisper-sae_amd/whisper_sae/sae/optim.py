@@ -79,15 +79,21 @@ class FusedAdamW(Optimizer):
         super().zero_grad(set_to_none=set_to_none)
 
     @torch.no_grad()
-    def step(self, closure=None, *, precision: int = N.PREC_FP32, max_norm: float = 0.0, grad_scale: float = 1.0,
-             normalize_decoder: bool = False, batch: int = 64, norm_from_wgrad: bool = False, dead_scan: bool = False,
-             stats_ptr: int = 0):
-        """Apply one update from ``self.grads`` (filled by ``wsae_weight_grads``).
+    def step(self, closure=None, **kw):
+        """Apply one update from ``self.grads`` (filled by ``wsae_weight_grads``); keyword arguments as ``apply_update``.
+        (This is torch's hooked / profiled ``Optimizer.step`` entry; the trainer calls ``apply_update`` directly - the
+        wrapper torch puts around ``step`` costs ~10 us of host time per call, which is a third of a small-batch step.)"""
+        if closure is not None:
+            raise NotImplementedError("FusedAdamW does not take a closure")
+        return self.apply_update(**kw)
+
+    def apply_update(self, *, precision: int = N.PREC_FP32, max_norm: float = 0.0, grad_scale: float = 1.0,
+                     normalize_decoder: bool = False, batch: int = 64, norm_from_wgrad: bool = False, dead_scan: bool = False,
+                     stats_ptr: int = 0):
+        """One fused update (clip -> AdamW -> renorm -> shadows -> dead scan) enqueued on the current stream.
 
         ``stats_ptr``: device address of the step record to fill (default: the engine's own record).
         """
-        if closure is not None:
-            raise NotImplementedError("FusedAdamW does not take a closure")
         eng = self.module.bind()
         self._ensure_state(eng)
         g = self.param_groups[0]
@@ -103,10 +109,20 @@ class FusedAdamW(Optimizer):
                                         int(mod.dead_feature_threshold) if dead_scan else 0,
                                         stats_ptr or eng.stats.data_ptr(), eng.stream()), "wsae_adamw_step")
         eng.mark_fresh(precision)
-        for st in self.state.values():
-            if "step" in st:
-                st["step"].fill_(float(self._t))
+        self._opt_called = True  # (what torch's wrapper around step() records for the scheduler's step-order check)
+        self._steps_dirty = True  # the per-parameter "step" tensors of the torch state are refreshed when somebody looks
         return None
+
+    def _sync_steps(self) -> None:
+        if getattr(self, "_steps_dirty", False):
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"].fill_(float(self._t))
+            self._steps_dirty = False
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
 
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)

@@ -20,6 +20,7 @@ Documented divergences from the reference:
 
 from __future__ import annotations
 
+import bisect
 import json
 from dataclasses import dataclass, fields
 from pathlib import Path
@@ -154,6 +155,9 @@ class SAETrainer:
         self._resample_dataset = None
         self._records = _MetricsRing()
         self._tracks_dead = hasattr(model, "get_dead_feature_ratio")
+        self._clip = float(config.gradient_clip)
+        self._sched_fast = all(hasattr(LinearLR, a) for a in ("get_lr", "_update_lr")) and \
+            hasattr(SequentialLR, "get_last_lr")  # (the attributes the lean scheduler step touches exist in this torch)
 
     # -- resampling (reference training.py:89-134; see module docstring) ---------------------------
     def set_resample_dataset(self, dataset) -> None:
@@ -201,6 +205,36 @@ class SAETrainer:
         decay = CosineAnnealingLR(self.optimizer, T_max=total_steps - warm, eta_min=0.1 * self.config.learning_rate)
         self.scheduler = SequentialLR(self.optimizer, schedulers=[ramp, decay], milestones=[warm])
 
+    def _scheduler_step(self) -> None:
+        """``self.scheduler.step()`` without its per-call bookkeeping (warning filters, context managers, the counter
+        wrapper: ~25 us of host time, a quarter of a small-batch step).  The objects are torch's own and stay exactly in
+        sync - ``last_epoch``, ``_step_count``, ``_last_lr`` advance as ``step()`` advances them and the new rate comes from
+        the active child's own ``get_lr()`` - so ``state_dict()`` / ``get_last_lr()`` / a later plain ``.step()`` see what they
+        would have seen (``tests/test_host_logic.py`` holds the two paths bit-equal over every G5 schedule).  Anything that is
+        not the ``SequentialLR(LinearLR, CosineAnnealingLR)`` this trainer builds goes through ``step()``."""
+        sch = self.scheduler
+        kids = getattr(sch, "_schedulers", None)
+        if (type(sch) is not SequentialLR or kids is None or len(kids) != 2 or type(kids[0]) is not LinearLR
+                or type(kids[1]) is not CosineAnnealingLR or not self._sched_fast):
+            sch.step()
+            return
+        sch.last_epoch += 1
+        idx = bisect.bisect_right(sch._milestones, sch.last_epoch)
+        kid = kids[idx]
+        if idx > 0 and sch._milestones[idx - 1] == sch.last_epoch:
+            kid._update_lr(0)  # the hand-over step (once per run): torch's own path
+        else:
+            kid._step_count += 1
+            kid.last_epoch += 1
+            kid._get_lr_called_within_step = True
+            try:
+                lr = kid.get_lr()[0]
+            finally:
+                kid._get_lr_called_within_step = False
+            self.optimizer.param_groups[0]["lr"] = lr
+            kid._last_lr = [lr]
+        sch._last_lr = kid._last_lr
+
     # -- the step ------------------------------------------------------------------------------------
     def train_step(self, batch) -> TrainingMetrics:
         """One optimisation step on ``batch`` ([B, D] tensor, or a tuple/list whose first item is one).
@@ -209,7 +243,8 @@ class SAETrainer:
         the kernels gather the rows straight from the on-device ring buffer.
         """
         model = self.model
-        model.train()
+        if not model.training:
+            model.train()
         rows = None
         if isinstance(batch, RingBatch):
             x, rows = batch.data, batch.rows
@@ -254,12 +289,12 @@ class SAETrainer:
             grad_scale = self._ddp_backward(eng, handle, opt, x, xd, rp, w, B, chunk, slot, stats, st)
         eng.generation += 1
         fused_norm = True  # the norm partials come with the gradients: from wsae_weight_grads, or from the wire unpack
-        opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=grad_scale,
-                 normalize_decoder=True, batch=B, norm_from_wgrad=fused_norm, dead_scan=True,
-                 stats_ptr=stats)
+        opt.apply_update(precision=prec, max_norm=self._clip, grad_scale=grad_scale,
+                         normalize_decoder=True, batch=B, norm_from_wgrad=fused_norm, dead_scan=True,
+                         stats_ptr=stats)
         self._token = model.param_token()
         if self.scheduler is not None:
-            self.scheduler.step()
+            self._scheduler_step()
         self.global_step += 1
         metrics = _PendingMetrics(chunk, slot, torch.cuda.current_stream(eng.device), opt.param_groups[0]["lr"],
                                   self.global_step)
@@ -314,23 +349,24 @@ class SAETrainer:
         if fp8 and prec != N.PREC_BF16:
             raise N.WsaeError("ReLUSAE(precision='fp8') trains with TrainingConfig.use_amp = True (the fp8 forward belongs to the bf16 mode)")
         N.check(lib.wsae_ctx_set_relu_fp8(handle, fp8), "wsae_ctx_set_relu_fp8")
-        w = eng.relu_work(B)
+        w = eng.relu_work(B, handle)
         pk, xd, rp = eng.pack.data_ptr(), _dtype_code(x), N.ptr(rows)
         chunk, slot = self._records.next(eng.device)
         stats = chunk.dev.data_ptr() + slot * N.STATS_WORDS * 4
         weight = float(model.sparsity_weight)
-        N.check(lib.wsae_relu_forward(handle, pk, x.data_ptr(), xd, rp, B, weight, w["hidden"].data_ptr(),
+        hid = N.ptr(w["hidden"])  # NULL where the kernels keep the hidden code as bf16 in their own workspace
+        N.check(lib.wsae_relu_forward(handle, pk, x.data_ptr(), xd, rp, B, weight, hid,
                                       w["recon"].data_ptr(), stats, 0, st), "wsae_relu_forward")
-        N.check(lib.wsae_relu_backward(handle, pk, x.data_ptr(), xd, rp, B, weight, w["hidden"].data_ptr(),
+        N.check(lib.wsae_relu_backward(handle, pk, x.data_ptr(), xd, rp, B, weight, hid,
                                        w["recon"].data_ptr(), opt.grads.data_ptr(), st), "wsae_relu_backward")
         eng.generation += 1
         grad_scale = sync_gradients(opt.grads, self._exchange_dtype) if world()[1] > 1 else 1.0
-        opt.step(precision=prec, max_norm=float(self.config.gradient_clip), grad_scale=grad_scale,
-                 normalize_decoder=bool(model.normalize_decoder), batch=B, norm_from_wgrad=False, dead_scan=False,
-                 stats_ptr=stats)
+        opt.apply_update(precision=prec, max_norm=self._clip, grad_scale=grad_scale,
+                         normalize_decoder=bool(model.normalize_decoder), batch=B, norm_from_wgrad=False, dead_scan=False,
+                         stats_ptr=stats)
         self._token = model.param_token()
         if self.scheduler is not None:
-            self.scheduler.step()
+            self._scheduler_step()
         self.global_step += 1
         return _PendingMetrics(chunk, slot, torch.cuda.current_stream(eng.device), opt.param_groups[0]["lr"],
                                self.global_step, sparsity_weight=weight)
