@@ -210,7 +210,8 @@ int wsae_input_grad(wsae_ctx* ctx, const float* params, const int32_t* idx, cons
  * grads are scaled by grad_scale first (1/world_size after a SUM all-reduce).
  * norm_from_wgrad: 1 = `grads` is exactly what the preceding wsae_weight_grads on this ctx wrote
  *   (single GPU): the global norm comes from the partial sums that call left behind and one pass
- *   over the gradients is saved; 0 = the gradients were touched since (all-reduce): recompute.
+ *   over the gradients is saved; 0 = the gradients were touched since (all-reduce): recompute; 2 = use the partial sums
+ *   if the preceding backward on this ctx left any (wsae_relu_backward does on its row-major-GEMM flow), else recompute.
  * last_activated (nullable) / step_count / dead_threshold: when given, stats->dead_count and
  *   stats->dead_ratio are written (get_dead_feature_ratio() of training.py:212).
  * All four buffers use the flat pack layout. */

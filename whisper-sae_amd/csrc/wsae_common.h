@@ -245,6 +245,7 @@ __device__ __forceinline__ float load_act(const void* p, int64_t i) {
 
 // internal (wsae_encode.hip): stage the batch (xb, xT) and run the dense encoder GEMM into pre [B][H]
 int wsae_internal_stage(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, hipStream_t st);
+int wsae_internal_stage_rows(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, hipStream_t st);
 int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,
                                  int B, float* pre, int64_t* step_count, int direct, hipStream_t st);
 // internal (wsae_encode.hip): the standalone TopK launch over ctx->pre; whether the strip-guided form applies
@@ -272,7 +273,9 @@ struct GxEpi {
     float* c;              // PLAIN: fp32 C [M][ldc] (+ z * cz);  RELU: optional fp32 copy of hidden (nullable)
     int64_t ldc, cz;
     bf16_t* out16;         // RELU: hidden bf16 [M][ld16];  DPRE: dpre bf16 [M][ld16]
-    const bf16_t* mask16;  // DPRE: hidden bf16 [M][ld16]
+    uint64_t* bits;        // RELU (out) / DPRE (in): [M][ldbits] words, one per (row, 64-column span of a wave tile): bit 16 c + j =
+                           // (hidden > 0) at column 64 w + 4 j + c - the dpre mask at 1/16 of the bytes of re-reading bf16 hidden
+    int64_t ldbits;
     int64_t ld16;
     const float* colw;     // RELU / DPRE: per-column weights of the L1 term (nullable = 1)
     float l1;              // DPRE: sparsity_weight / (B H)

@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(256) stage_batch_kernel(const void* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) tile[bl][4 * q + i] = v[i];
     }
+    if (!xT) return;  // (callers that read the staged rows row-major only: the ReLU path's row-major-GEMM flow)
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -572,15 +573,16 @@ static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // kernel of the forward reads it (the decode launch stamps last_activated with the advanced value)
 template <typename T>
 static int stage_batch(wsae_ctx* c, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,
-                       int64_t* step_count, hipStream_t st) {
+                       int64_t* step_count, hipStream_t st, bool want_xT = true) {
     const int D = c->D;
     const int ldT = round_up(B, 128);
     dim3 sg(ceil_div(ldT, 64), ceil_div(D, 64));
+    T* xT = want_xT ? (T*)c->xT : nullptr;
     WSAE_PROF_BEGIN(c, WSAE_K_STAGE_BATCH, st);
     if (x_dtype == WSAE_DT_F32)
-        stage_batch_kernel<WSAE_DT_F32, T><<<sg, 256, 0, st>>>(x, rows, params + c->off[4], (T*)c->xb, (T*)c->xT, B, D, ldT, step_count);
+        stage_batch_kernel<WSAE_DT_F32, T><<<sg, 256, 0, st>>>(x, rows, params + c->off[4], (T*)c->xb, xT, B, D, ldT, step_count);
     else
-        stage_batch_kernel<WSAE_DT_BF16, T><<<sg, 256, 0, st>>>(x, rows, params + c->off[4], (T*)c->xb, (T*)c->xT, B, D, ldT, step_count);
+        stage_batch_kernel<WSAE_DT_BF16, T><<<sg, 256, 0, st>>>(x, rows, params + c->off[4], (T*)c->xb, xT, B, D, ldT, step_count);
     WSAE_PROF_END(c, WSAE_K_STAGE_BATCH, st);
     WSAE_LAUNCH_CHECK();
     return WSAE_OK;
@@ -691,6 +693,13 @@ int wsae_internal_stage(wsae_ctx* ctx, const float* params, const void* x, int x
                                                 : stage_batch<float>(ctx, params, x, x_dtype, rows, B, nullptr, st);
     if (rc == WSAE_OK) ctx->xT_valid = 1;
     return rc;
+}
+
+// xb alone (no transposed copy): for callers that read the staged rows row-major (wsae_relu.hip, row-major-GEMM flow)
+int wsae_internal_stage_rows(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, hipStream_t st) {
+    ctx->xT_valid = 0;
+    return ctx->prec == WSAE_PREC_BF16 ? stage_batch<bf16_t>(ctx, params, x, x_dtype, rows, B, nullptr, st, false)
+                                       : stage_batch<float>(ctx, params, x, x_dtype, rows, B, nullptr, st, false);
 }
 
 int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,

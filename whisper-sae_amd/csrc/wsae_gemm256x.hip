@@ -150,6 +150,16 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
         if (EPI != GX_EPI_PLAIN && e.colw && col_ok) w4 = *(const float4*)(e.colw + ncol);
         float s_l1 = 0.f, s_cnt = 0.f;                 // RELU partials
         float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);  // DPRE column sums (this lane's rows)
+        const int64_t widx = (n0 + wn * 64) >> 6;        // this wave's word of a row's activity bits
+        // DPRE: the activity bits of the wave tile's 128 rows, two rows per lane, requested before the patches are touched
+        uint64_t mw0 = 0, mw1 = 0;
+        if constexpr (EPI == GX_EPI_DPRE) {
+            const int ra = min(m0 + wm * 128 + lane, M - 1), rb = min(m0 + wm * 128 + 64 + lane, M - 1);
+            if (n0 + wn * 64 < N) {
+                mw0 = e.bits[(int64_t)ra * e.ldbits + widx];
+                mw1 = e.bits[(int64_t)rb * e.ldbits + widx];
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -178,14 +188,29 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
                         s_l1 += (v.x * w4.x + v.y * w4.y) + (v.z * w4.z + v.w * w4.w);
                         s_cnt += (float)((v.x > 0.f) + (v.y > 0.f) + (v.z > 0.f) + (v.w > 0.f));
                     }
+                    // activity bits of this instruction's 4 rows (every lane takes part in the ballots; rows / columns past the
+                    // matrix vote 0); the first lane of a row's 16 writes the row's word.  (bf16 keeps fp32's exponent range: a
+                    // positive hidden value stays positive when it is rounded, so these are also the bits of bf16(hidden) > 0.)
+                    {
+                        const unsigned long long bx = __ballot(ok && v.x > 0.f), by = __ballot(ok && v.y > 0.f);
+                        const unsigned long long bz = __ballot(ok && v.z > 0.f), bw = __ballot(ok && v.w > 0.f);
+                        const int sh = 16 * pr;
+                        const unsigned long long word = ((bx >> sh) & 0xFFFFull) | (((by >> sh) & 0xFFFFull) << 16) |
+                                                        (((bz >> sh) & 0xFFFFull) << 32) | (((bw >> sh) & 0xFFFFull) << 48);
+                        if ((lane & 15) == 0 && m < M && n0 + wn * 64 < N) e.bits[(int64_t)m * e.ldbits + widx] = word;
+                    }
                 } else {
                     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+                    // this row's word sits in lane (32 mi + 4 i + pr) & 63 of mw0 (rows 0..63 of the wave tile) or mw1
+                    const int srcl = (32 * mi + 4 * i + pr) & 63;
+                    const unsigned long long mw = mi < 2 ? mw0 : mw1;
+                    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mw, srcl, 64), hi = (uint32_t)__shfl((int)(uint32_t)(mw >> 32), srcl, 64);
+                    const int j = lane & 15;
                     if (ok) {
-                        const bf16x4 hm = *(const bf16x4*)(e.mask16 + (int64_t)m * e.ld16 + ncol);
-                        d.x = (float)hm[0] > 0.f ? v.x + e.l1 * w4.x : 0.f;
-                        d.y = (float)hm[1] > 0.f ? v.y + e.l1 * w4.y : 0.f;
-                        d.z = (float)hm[2] > 0.f ? v.z + e.l1 * w4.z : 0.f;
-                        d.w = (float)hm[3] > 0.f ? v.w + e.l1 * w4.w : 0.f;
+                        d.x = ((lo >> j) & 1u) ? v.x + e.l1 * w4.x : 0.f;
+                        d.y = ((lo >> (16 + j)) & 1u) ? v.y + e.l1 * w4.y : 0.f;
+                        d.z = ((hi >> j) & 1u) ? v.z + e.l1 * w4.z : 0.f;
+                        d.w = ((hi >> (16 + j)) & 1u) ? v.w + e.l1 * w4.w : 0.f;
                         bf16x4 o;
                         o[0] = (bf16_t)d.x; o[1] = (bf16_t)d.y; o[2] = (bf16_t)d.z; o[3] = (bf16_t)d.w;
                         *(bf16x4*)(e.out16 + (int64_t)m * e.ld16 + ncol) = o;

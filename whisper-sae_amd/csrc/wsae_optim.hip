@@ -426,6 +426,7 @@ extern "C" int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads,
     const int64_t n4 = ctx->P / 4;
     int nparts;
     float part_scale;
+    if (norm_from_wgrad == 2) norm_from_wgrad = ctx->n_sq_parts > 0 ? 1 : 0;  // "if the backward left them" (the ReLU path's two flows)
     if (norm_from_wgrad) {  // partial sums of squares were left by wsae_weight_grads (grads untouched since)
         WSAE_REQUIRE(ctx->n_sq_parts > 0, "wsae_adamw_step: norm_from_wgrad without a preceding wsae_weight_grads");
         nparts = ctx->n_sq_parts;

@@ -395,6 +395,35 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ p
     out[n] = a;
 }
 
+// Both bias gradients in ONE launch with the rows of a column spread over the block (the form above walks a column's rows in
+// one thread: 17 us per call at B = 16384 for a few hundred KB).  Block = 64 columns x 4 row parts, every thread sums its
+// rows 8 loads at a time, the four part sums meet in LDS in fixed order.  Blocks [0, nb1) serve (part1, N1), the rest (part2, N2).
+__global__ void __launch_bounds__(256)
+colsum2_kernel(const float* __restrict__ part1, int nrows1, int N1, float* __restrict__ out1, int nb1,
+               const float* __restrict__ part2, int nrows2, int N2, float* __restrict__ out2) {
+    __shared__ float s[4][64];
+    const bool second = (int)blockIdx.x >= nb1;
+    const float* part = second ? part2 : part1;
+    const int nrows = second ? nrows2 : nrows1, N = second ? N2 : N1;
+    float* out = second ? out2 : out1;
+    const int c = threadIdx.x & 63, rp = threadIdx.x >> 6;
+    const int n = ((int)blockIdx.x - (second ? nb1 : 0)) * 64 + c;
+    const int per = (nrows + 3) / 4, r0 = rp * per, r1 = min(nrows, r0 + per);
+    float a = 0.f;
+    if (n < N) {
+        for (int i0 = r0; i0 < r1; i0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = part[(int64_t)min(i0 + i, r1 - 1) * N + n];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a += (i0 + i < r1) ? v[i] : 0.f;
+        }
+    }
+    s[rp][c] = a;
+    __syncthreads();
+    if (rp == 0 && n < N) out[n] = (s[0][c] + s[1][c]) + (s[2][c] + s[3][c]);
+}
+
 __global__ void __launch_bounds__(256)
 slab_sum_kernel(const float* __restrict__ slabs, int64_t slab_stride, int nz, int64_t n4, float* __restrict__ grads,
                 float* __restrict__ g_bpre, int D) {
@@ -408,6 +437,45 @@ slab_sum_kernel(const float* __restrict__ slabs, int64_t slab_stride, int nz, in
     }
     if (blockIdx.x == 0)
         for (int d = threadIdx.x; d < D; d += 256) g_bpre[d] = 0.f;  // no pre-bias in this module: it stays exactly 0
+}
+
+// The same sum with every slab's load of an element in flight at once (the loop above issues them one dependent trip at a
+// time), one float4 per thread and pass, and the block's sum of squares left as a global-norm partial: the optimizer then
+// needs no norm pass over the matrices (wsae_adamw_step norm_from_wgrad = 1; the bias gradients' squares are added by
+// bias_sq_kernel below).  nz <= 8.
+__global__ void __launch_bounds__(256)
+slab_sum8_kernel(const float* __restrict__ slabs, int64_t slab_stride, int nz, int64_t n4, float* __restrict__ grads,
+                 float* __restrict__ g_bpre, int D, float* __restrict__ part_sq) {
+    __shared__ float red[8];
+    float sq = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) v[z] = ((const float4*)(slabs + (int64_t)min(z, nz - 1) * slab_stride))[i];
+        float4 a = v[0];
+#pragma unroll
+        for (int z = 1; z < 8; ++z) {
+            const float w = z < nz ? 1.f : 0.f;
+            a.x = fmaf(w, v[z].x, a.x); a.y = fmaf(w, v[z].y, a.y); a.z = fmaf(w, v[z].z, a.z); a.w = fmaf(w, v[z].w, a.w);
+        }
+        ((float4*)grads)[i] = a;
+        sq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    }
+    if (blockIdx.x == 0)
+        for (int d = threadIdx.x; d < D; d += 256) g_bpre[d] = 0.f;  // no pre-bias in this module: it stays exactly 0
+    const float t = block_sum(sq, red);
+    if (threadIdx.x == 0) part_sq[blockIdx.x] = t;
+}
+
+// squares of the two bias gradients (H + D values) as one more norm partial
+__global__ void __launch_bounds__(256) bias_sq_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb,
+                                                      float* __restrict__ out) {
+    __shared__ float red[8];
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < na; i += 256) sq = fmaf(a[i], a[i], sq);
+    for (int i = threadIdx.x; i < nb; i += 256) sq = fmaf(b[i], b[i], sq);
+    const float t = block_sum(sq, red);
+    if (threadIdx.x == 0) *out = t;
 }
 
 int check_dims(wsae_ctx* ctx, int B, const char* who) {
@@ -485,7 +553,7 @@ int forward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     const int D = ctx->D, H = ctx->H;
     const int ldT = (B + 127) / 128 * 128;
     const ReluWs ws = host_ws(ctx);
-    int rc = wsae_internal_stage(ctx, params, x, x_dtype, rows, B, st);  // xb = bf16(x) [B][D] (the contractions read it row-major)
+    int rc = wsae_internal_stage_rows(ctx, params, x, x_dtype, rows, B, st);  // xb = bf16(x) [B][D] (the contractions read it row-major)
     if (rc) return rc;
     GxEpi e1 = {};
     e1.bias = params + ctx->off[2];
@@ -493,6 +561,7 @@ int forward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     e1.out16 = (bf16_t*)ws.hid; e1.ld16 = H;
     e1.colw = ctx->relu_l1w;
     e1.part = ws.part; e1.nslots = ws.nblk;
+    e1.bits = (uint64_t*)ws.dpreT; e1.ldbits = ceil_div(H, 64);  // (the transposed-dpre buffer of the general path is free in this flow)
     WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 0, GX_EPI_RELU, ctx->xb, D, ctx->We_bf16, D, B, H, D, 1, e1, st),
                  "wsae_relu_forward: encoder GEMM rejected B %d, D %d, H %d", B, D, H);
     GxEpi e2 = {};
@@ -531,7 +600,8 @@ int backward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
                                                                     ws.part + 2 * ws.nblk);
     bf16_t* dpre = (bf16_t*)ws.hidT;  // [B][H] (the transposed-hidden buffer of the general path is free in this flow)
     GxEpi e3 = {};
-    e3.out16 = dpre; e3.mask16 = (const bf16_t*)ws.hid; e3.ld16 = H;
+    e3.out16 = dpre; e3.ld16 = H;
+    e3.bits = (uint64_t*)ws.dpreT; e3.ldbits = ceil_div(H, 64);  // the activity bits the forward's epilogue left: 1/16 of re-reading hidden
     e3.colw = ctx->relu_l1w;
     e3.l1 = weight / ((float)B * (float)H);
     e3.colpart = ws.colpart;
@@ -547,11 +617,14 @@ int backward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
     e5.c = ctx->wg_slabs + hd;
     WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 1, 1, GX_EPI_PLAIN, ws.hid, H, ctx->gb, D, H, D, B, nz, e5, st),
                  "wsae_relu_backward: dW_d contraction rejected B %d (split %d)", B, nz);
-    slab_sum_kernel<<<512, 256, 0, st>>>(ctx->wg_slabs, slab_stride, nz, slab_stride / 4, grads, grads + ctx->off[4], D);
-    colsum_kernel<<<ceil_div(H, 256), 256, 0, st>>>(ws.colpart, B / 128, H, grads + ctx->off[2]);
-    colsum_kernel<<<ceil_div(D, 256), 256, 0, st>>>(ctx->part_dbd, ceil_div(B, 64), D, grads + ctx->off[3]);
+    const int nsb = 1022;  // (blocks = norm partial slots; + 1 for the biases, WSAE_MAX_PARTIALS = 1024)
+    slab_sum8_kernel<<<nsb, 256, 0, st>>>(ctx->wg_slabs, slab_stride, nz, slab_stride / 4, grads, grads + ctx->off[4], D, ctx->part_sq);
+    const int nb1 = ceil_div(H, 64);
+    colsum2_kernel<<<nb1 + ceil_div(D, 64), 256, 0, st>>>(ws.colpart, B / 128, H, grads + ctx->off[2], nb1, ctx->part_dbd,
+                                                          ceil_div(B, 64), D, grads + ctx->off[3]);
+    bias_sq_kernel<<<1, 256, 0, st>>>(grads + ctx->off[2], H, grads + ctx->off[3], D, ctx->part_sq + nsb);
     WSAE_LAUNCH_CHECK();
-    ctx->n_sq_parts = 0;
+    ctx->n_sq_parts = nsb + 1;  // wsae_adamw_step(norm_from_wgrad = 1) sums these: no separate norm pass
     ctx->g_is_bf16 = 1;
     return WSAE_OK;
 }

@@ -103,7 +103,7 @@ class FusedAdamW(Optimizer):
         N.check(eng.lib.wsae_adamw_step(handle, eng.pack.data_ptr(), self.grads.data_ptr(), self._m.data_ptr(),
                                         self._v.data_ptr(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                         float(g["eps"]), float(g["weight_decay"]), self._t, float(max_norm),
-                                        float(grad_scale), 1 if normalize_decoder else 0, 1 if norm_from_wgrad else 0,
+                                        float(grad_scale), 1 if normalize_decoder else 0, int(norm_from_wgrad),
                                         mod.feature_last_activated.data_ptr() if dead_scan else 0,
                                         mod.step_count.data_ptr() if dead_scan else 0,
                                         int(mod.dead_feature_threshold) if dead_scan else 0,

@@ -360,10 +360,13 @@ class SAETrainer:
         N.check(lib.wsae_relu_backward(handle, pk, x.data_ptr(), xd, rp, B, weight, hid,
                                        w["recon"].data_ptr(), opt.grads.data_ptr(), st), "wsae_relu_backward")
         eng.generation += 1
-        grad_scale = sync_gradients(opt.grads, self._exchange_dtype) if world()[1] > 1 else 1.0
+        ddp = world()[1] > 1
+        grad_scale = sync_gradients(opt.grads, self._exchange_dtype) if ddp else 1.0
+        # norm_from_wgrad = 2: take the global-norm partials the backward left when it did (single process only: an exchange
+        # rewrites the gradients)
         opt.apply_update(precision=prec, max_norm=self._clip, grad_scale=grad_scale,
-                         normalize_decoder=bool(model.normalize_decoder), batch=B, norm_from_wgrad=False, dead_scan=False,
-                         stats_ptr=stats)
+                         normalize_decoder=bool(model.normalize_decoder), batch=B, norm_from_wgrad=0 if ddp else 2,
+                         dead_scan=False, stats_ptr=stats)
         self._token = model.param_token()
         if self.scheduler is not None:
             self._scheduler_step()
