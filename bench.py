@@ -288,6 +288,7 @@ def main() -> None:
             if dominant and dominant in names and names[dominant][0]:
                 roof = roofline_object(dominant, names[dominant][0], names[dominant][1], B, traffic_of(dominant), lps(dominant))
                 roof["selected_by"] = "longest average launch in the probe window (HIP events around every kernel)"
+                roof["kernel"] = pmc_names.get(dominant, dominant) + f"<{args.precision}>"
             src = prof if "wgrad" in prof else probe
             if "wgrad" in src and src["wgrad"][0]:
                 roof_wgrad = roofline_object("wgrad", src["wgrad"][0], src["wgrad"][1], B, traffic_of("wgrad"), lps("wgrad"))

@@ -190,6 +190,11 @@ int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t
 #define WSAE_PART_DECODER 0
 #define WSAE_PART_ENCODER 1
 int wsae_wgrad_parts_supported(const wsae_ctx* ctx);
+/* Compute units the ENCODER part leaves without a workgroup (default 0).  The contraction's workgroups fill the register
+ * file of the CU they sit on (two waves x ~246 VGPRs per SIMD), so the collective of the decoder half, issued on another
+ * stream while the encoder part runs, only overlaps if some CUs are free for its kernels; the part then runs split-K 13
+ * or 14 instead of 16 (a few percent longer).  Unmeasured on hardware so far: the builder's boxes have one GPU. */
+int wsae_ctx_set_comm_reserve(wsae_ctx* ctx, int32_t n_cus);
 int wsae_weight_grads_wire(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                            const int32_t* rows, const float* vals, const int32_t* idx, const float* dpre,
                            int32_t B, int32_t part, void* wire, int32_t wire_dtype, void* stream);

@@ -70,6 +70,7 @@ struct wsae_ctx {
     const float* relu_l1w;  // per-feature weights of the ReLU path's L1 term (nullable; caller-owned [H] floats)
     int loss_cols;        // columns the MSE averages over (= D; transcoders with a narrower output pad D and set this)
     int cus;              // compute units of `device` (persistent-kernel grid size)
+    int comm_reserve;     // CUs the encoder half of a data-parallel backward leaves free for the collective running beside it
     int64_t P;            // flat pack element count
     int64_t off[5];       // W_e, W_dT, b_e, b_d, b_pre
     // ---- derived shadows -------------------------------------------------------------------

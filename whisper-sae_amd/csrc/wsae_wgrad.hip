@@ -885,8 +885,10 @@ grad_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ db
 // split; every split also costs one slab written and re-read (the small per-split term).  At
 // H = 3072, D = 384, B = 16384 (wgrad2_kernel: 32 tiles, one workgroup per CU) this picks 8: 256 workgroups,
 // one round of 32 chunks; one matrix per launch (16 tiles, max_split 16) gets 16.
-static int pick_nsplit(wsae_ctx* ctx, int tiles, int nchunks, int nt, int max_split) {
-    const int resident = ctx->cus * (nt == 1 ? 2 : 1);  // LDS: 72 KB per workgroup at NT = 1, 108 / 144 KB above
+static int pick_nsplit(wsae_ctx* ctx, int tiles, int nchunks, int nt, int max_split, int reserve_cus = 0) {
+    // (reserve_cus: compute units left without a workgroup of this launch - the contraction's workgroups fill a CU's register
+    // file, so a collective that is meant to run UNDER the launch needs CUs of its own: wsae_ctx_set_comm_reserve)
+    const int resident = max(1, ctx->cus - reserve_cus) * (nt == 1 ? 2 : 1);  // LDS: 72 KB per workgroup at NT = 1, 108 / 144 KB above
     int best = 1;
     int64_t best_cost = INT64_MAX;
     for (int ns = 1; ns <= max_split; ++ns) {
@@ -921,7 +923,8 @@ static WgPlan plan_wgrad(wsae_ctx* ctx, int B, int part) {
     p.which0 = part == WSAE_PART_ENCODER ? 1 : 0;
     p.nslots = part == WSAE_PART_ALL ? WSAE_WGRAD_MAX_SPLIT : 2 * WSAE_WGRAD_MAX_SPLIT;
     p.dec_row_base = part == WSAE_PART_ALL ? H : 0;
-    p.nsplit = pick_nsplit(ctx, p.ntm * p.ntn * p.nwhich, p.nchunks, p.nt, p.nslots);
+    // the encoder half of a data-parallel backward runs beside the all-reduce of the decoder half
+    p.nsplit = pick_nsplit(ctx, p.ntm * p.ntn * p.nwhich, p.nchunks, p.nt, p.nslots, part == WSAE_PART_ENCODER ? ctx->comm_reserve : 0);
     p.rm = sizeof(T) == 2 && p.nt == 0 && ctx->g_is_bf16 && D % 8 == 0;
     return p;
 }
@@ -936,15 +939,15 @@ static void launch_wgrad(wsae_ctx* ctx, const WgPlan& p, hipStream_t st, const f
     // xb or - when the encoder GEMM gathered its rows itself - the caller's bf16 rows through the row list.  Then the
     // bucket launch is the counting sort alone: no g -> gT / x -> xT blocks.
     const bool rm = p.rm;
-    if (sort_code) {
+    // (the decode launch of this batch may have sorted the code itself - chunked form, wsae_decode_mfma.hip: then nothing is launched)
+    const bool presorted = rm && ctx->ent_valid && ctx->ent_vals == vals && ctx->ent_B == B;
+    if (sort_code && !presorted) {
         WSAE_PROF_BEGIN(ctx, WSAE_K_BUCKET, st);
         // otherwise: + the transposition of g (left row-major by the decode launch) as a second kind of block in the same launch
         // ... and, when no staging launch left xT (the encoder GEMM gathered the batch rows itself), of x as a third kind
         const int ntr = rm ? 0 : (ldT / 64) * ceil_div(ctx->D, 64);
         const int nxt = ctx->xT_valid ? 0 : ntr;
-        if (rm && ctx->ent_valid && ctx->ent_vals == vals && ctx->ent_B == B) {
-            // the decode launch of this batch sorted the code itself (chunked form, wsae_decode_mfma.hip): nothing to launch
-        } else if (rm && KT * ctx->K <= 4096)
+        if (rm && KT * ctx->K <= 4096)
             bucket_sort_kernel<T><<<nchunks, 1024, 0, st>>>(vals, idx, dpre, B, ctx->K, ntm, W2_M, ctx->ent_pos, (T*)ctx->ent_hid,
                                                             (T*)ctx->ent_dpre, ctx->ent_off);
         else
@@ -1063,6 +1066,12 @@ extern "C" int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void*
 }
 
 extern "C" int wsae_wgrad_parts_supported(const wsae_ctx* ctx) { return (ctx && ctx->D > 256) ? 1 : 0; }
+
+extern "C" int wsae_ctx_set_comm_reserve(wsae_ctx* ctx, int32_t n_cus) {
+    WSAE_REQUIRE(ctx && n_cus >= 0 && n_cus < ctx->cus, "wsae_ctx_set_comm_reserve: %d compute units of %d", n_cus, ctx ? ctx->cus : 0);
+    ctx->comm_reserve = n_cus;
+    return WSAE_OK;
+}
 
 extern "C" int wsae_weight_grads_wire(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
                                       const int32_t* rows, const float* vals, const int32_t* idx, const float* dpre,

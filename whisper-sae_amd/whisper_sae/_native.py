@@ -67,6 +67,7 @@ SIGNATURES = {
     "wsae_last_residual_grad": (C.c_int, [_p, _i32, _p, _p]),
     "wsae_input_grad": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i32, _p]),
     "wsae_wgrad_parts_supported": (C.c_int, [_p]),
+    "wsae_ctx_set_comm_reserve": (C.c_int, [_p, _i32]),
     "wsae_weight_grads_wire": (C.c_int, [_p, _p, _p, _i32, _p, _p, _p, _p, _i32, _i32, _p, _i32, _p]),
     "wsae_grads_unpack_wire": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _p, _p]),
     "wsae_adamw_step": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _i32, _i32,

@@ -84,6 +84,9 @@ class TrainingConfig(BaseModel):
                                                  "gradient; bf16 = half the bytes over xGMI, every rank's gradient rounded "
                                                  "once to bf16 and summed in bf16 (opt-in: it changes the step); auto = bf16 "
                                                  "when use_amp, fp32 otherwise")
+    ddp_comm_reserve_cus: int = Field(24, ge=0, le=128,
+                                      description="data-parallel runs only: compute units the encoder half of the backward leaves "
+                                                  "free so that the all-reduce of the decoder half can run beside it (0 = none)")
 
 
 class DataConfig(BaseModel):

@@ -329,6 +329,10 @@ class SAETrainer:
         ex.start(met)
         args = (handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(), w["dpre"].data_ptr(), B)
         if lib.wsae_wgrad_parts_supported(handle):
+            if getattr(self, "_reserve_set", None) != handle:  # once per ctx
+                N.check(lib.wsae_ctx_set_comm_reserve(handle, int(getattr(self.config, "ddp_comm_reserve_cus", 0))),
+                        "wsae_ctx_set_comm_reserve")
+                self._reserve_set = handle
             N.check(lib.wsae_weight_grads_wire(*args, N.PART_DECODER, wire.data_ptr(), wire_dt, st), "wsae_weight_grads_wire")
             ex.start(wire[:hd])
             N.check(lib.wsae_weight_grads_wire(*args, N.PART_ENCODER, wire.data_ptr(), wire_dt, st), "wsae_weight_grads_wire")
