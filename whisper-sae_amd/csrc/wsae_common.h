@@ -286,3 +286,6 @@ struct GxEpi {
 };
 bool wsae_internal_gemm256x(wsae_ctx* c, int a_rm, int b_rm, int epi, const void* A, int64_t lda, const void* Bm, int64_t ldb,
                             int M, int N, int K, int nsplit, const GxEpi& e, hipStream_t st);
+// internal (wsae_wgrad.hip): the ReLU SAE's two contractions on the 192 x 384 geometry + slab reduction; 0 = shape not served
+int wsae_internal_relu_wgrad(wsae_ctx* ctx, const void* hid, const void* dpre, const void* xb, const void* gb, int B, float* grads,
+                             hipStream_t st);

@@ -246,38 +246,55 @@ struct Mfma96<bf16_t, MI> {
     // RM = true : Bs is the row-major image [column block of 64][64 k rows][128 bytes], chunk c of row r at slot
     //             c ^ rm_swz(r) (wsae_wgrad.hip): a B fragment = two ds_read_b64_tr_b16, each 4 consecutive k of this
     //             lane's column (lane 4 q + p of a 16-lane group addresses block row q, columns 4 p .. 4 p + 3).
-    template <bool RM = false, typename F>
+    // ARM = true: As too is a row-major image [feature block of 64][64 k rows][128 bytes] (the dense left operand of the
+    //             ReLU SAE's contractions, wgrad2d_kernel): A fragments by transposed reads as well.
+    template <bool RM = false, bool ARM = false, typename F>
     static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
                                                 f32x16 (&acc)[MI][3], F&& between) {
         const int r = lane & 31, h = lane >> 5;
         const int sw = (r >> 1) & 7;  // a_row0, b_row0 and the 32-row steps are multiples of 32: they do not change the swizzle
         const char* ap = As + (a_row0 + r) * SWZ_ROW_BYTES;
         const char* bp = Bs + (b_row0 + r) * SWZ_ROW_BYTES;
-        const char* tp[3][2];  // RM: per column tile and 4-row block, the address for k step 0 (k steps are 2 KB apart)
-        if constexpr (RM) {
+        const char* tp[3][2];   // RM: per column tile and 4-row block, the address for k step 0 (k steps are 2 KB apart)
+        const char* tpa[MI][2];  // ARM: the same for the left operand's feature tiles
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+        auto rm_addr = [&](const char* img, int col0, int q2) -> const char* {
             const int i = lane & 15, g1 = (lane >> 4) & 1;
+            const int c0 = col0 + g1 * 16 + 4 * (i & 3);          // first of this lane's 4 address columns
+            const int cidx = (c0 & 63) >> 3;                      // 16-byte chunk inside the 128-byte row
+            const int row = 8 * h + 4 * q2 + (i >> 2);            // + 16 kk: does not change the swizzle
+            const int swz = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+            return img + (c0 >> 6) * 8192 + row * 128 + ((cidx ^ swz) << 4) + 8 * (i & 1);
+        };
+        if constexpr (RM) {
 #pragma unroll
-            for (int ni = 0; ni < 3; ++ni) {
-                const int c0 = b_row0 + ni * 32 + g1 * 16 + 4 * (i & 3);  // first of this lane's 4 address columns
-                const int cidx = (c0 & 63) >> 3;                          // 16-byte chunk inside the 128-byte row
+            for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    const int row = 8 * h + 4 * q2 + (i >> 2);            // + 16 kk: does not change the swizzle
-                    const int swz = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-                    tp[ni][q2] = Bs + (c0 >> 6) * 8192 + row * 128 + ((cidx ^ swz) << 4) + 8 * (i & 1);
-                }
-            }
+                for (int q2 = 0; q2 < 2; ++q2) tp[ni][q2] = rm_addr(Bs, b_row0 + ni * 32, q2);
+        }
+        if constexpr (ARM) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) tpa[mi][q2] = rm_addr(As, a_row0 + mi * 32, q2);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int co = ((kk * 2 + h) ^ sw) << 4;
             bf16x8 a[MI], b[3];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8*)(ap + i * 32 * SWZ_ROW_BYTES + co);
+            for (int i = 0; i < MI; ++i) {
+                if constexpr (ARM) {
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tpa[i][0] + kk * 2048));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tpa[i][1] + kk * 2048));
+                    a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                } else {
+                    a[i] = *(const bf16x8*)(ap + i * 32 * SWZ_ROW_BYTES + co);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 if constexpr (RM) {
-                    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tp[i][0] + kk * 2048));
                     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tp[i][1] + kk * 2048));
                     b[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -312,10 +329,10 @@ struct Mfma96<bf16_t, MI> {
 // same k permutation, so the contraction is unchanged.
 template <int MI>
 struct Mfma96<float, MI> {
-    template <bool RM = false, typename F>
+    template <bool RM = false, bool ARM = false, typename F>
     static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
                                                 f32x16 (&acc)[MI][3], F&& between) {
-        static_assert(!RM, "row-major dense operands need 16-bit transposed LDS reads: bf16 only");
+        static_assert(!RM && !ARM, "row-major dense operands need 16-bit transposed LDS reads: bf16 only");
         const int r = lane & 31, h = lane >> 5;
         const int sw = (r >> 1) & 7;
         const char* ap = As + (a_row0 + r) * SWZ_ROW_BYTES;

@@ -607,24 +607,31 @@ int backward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
     e3.colpart = ws.colpart;
     WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 0, GX_EPI_DPRE, ctx->gb, D, ctx->WdT_bf16, D, B, H, D, 1, e3, st),
                  "wsae_relu_backward: dh GEMM rejected B %d, D %d, H %d", B, D, H);
-    const int nz = x_split(B);
-    const int64_t hd = (int64_t)H * D, slab_stride = 2 * hd;
-    GxEpi e4 = {};
-    e4.c = ctx->wg_slabs; e4.ldc = D; e4.cz = slab_stride;
-    WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 1, 1, GX_EPI_PLAIN, dpre, H, ctx->xb, D, H, D, B, nz, e4, st),
-                 "wsae_relu_backward: dW_e contraction rejected B %d (split %d)", B, nz);
-    GxEpi e5 = e4;
-    e5.c = ctx->wg_slabs + hd;
-    WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 1, 1, GX_EPI_PLAIN, ws.hid, H, ctx->gb, D, H, D, B, nz, e5, st),
-                 "wsae_relu_backward: dW_d contraction rejected B %d (split %d)", B, nz);
-    const int nsb = 1022;  // (blocks = norm partial slots; + 1 for the biases, WSAE_MAX_PARTIALS = 1024)
-    slab_sum8_kernel<<<nsb, 256, 0, st>>>(ctx->wg_slabs, slab_stride, nz, slab_stride / 4, grads, grads + ctx->off[4], D, ctx->part_sq);
+    // the two contractions: wgrad2's 192 x 384 geometry with a dense left operand in ONE launch + the slab reduction of the
+    // TopK path (matrix rows + norm partials); the 256 x 256 GEMM twice for shapes that launch does not serve
+    int nsq = wsae_internal_relu_wgrad(ctx, ws.hid, dpre, ctx->xb, ctx->gb, B, grads, st);
+    if (nsq == 0) {
+        const int nz = x_split(B);
+        const int64_t hd = (int64_t)H * D, slab_stride = 2 * hd;
+        GxEpi e4 = {};
+        e4.c = ctx->wg_slabs; e4.ldc = D; e4.cz = slab_stride;
+        WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 1, 1, GX_EPI_PLAIN, dpre, H, ctx->xb, D, H, D, B, nz, e4, st),
+                     "wsae_relu_backward: dW_e contraction rejected B %d (split %d)", B, nz);
+        GxEpi e5 = e4;
+        e5.c = ctx->wg_slabs + hd;
+        WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 1, 1, GX_EPI_PLAIN, ws.hid, H, ctx->gb, D, H, D, B, nz, e5, st),
+                     "wsae_relu_backward: dW_d contraction rejected B %d (split %d)", B, nz);
+        nsq = 1022;  // (blocks = norm partial slots; + 1 for the biases, WSAE_MAX_PARTIALS = 1024)
+        slab_sum8_kernel<<<nsq, 256, 0, st>>>(ctx->wg_slabs, slab_stride, nz, slab_stride / 4, grads, grads + ctx->off[4], D, ctx->part_sq);
+    } else {
+        WSAE_HIP_CHECK(hipMemsetAsync(grads + ctx->off[4], 0, (size_t)D * sizeof(float), st));  // no pre-bias in this module: its gradient stays exactly 0
+    }
     const int nb1 = ceil_div(H, 64);
     colsum2_kernel<<<nb1 + ceil_div(D, 64), 256, 0, st>>>(ws.colpart, B / 128, H, grads + ctx->off[2], nb1, ctx->part_dbd,
                                                           ceil_div(B, 64), D, grads + ctx->off[3]);
-    bias_sq_kernel<<<1, 256, 0, st>>>(grads + ctx->off[2], H, grads + ctx->off[3], D, ctx->part_sq + nsb);
+    bias_sq_kernel<<<1, 256, 0, st>>>(grads + ctx->off[2], H, grads + ctx->off[3], D, ctx->part_sq + nsq);
     WSAE_LAUNCH_CHECK();
-    ctx->n_sq_parts = nsb + 1;  // wsae_adamw_step(norm_from_wgrad = 1) sums these: no separate norm pass
+    ctx->n_sq_parts = nsq + 1;  // wsae_adamw_step(norm_from_wgrad = 1) sums these: no separate norm pass
     ctx->g_is_bf16 = 1;
     return WSAE_OK;
 }

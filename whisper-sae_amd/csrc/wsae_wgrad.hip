@@ -552,7 +552,7 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
         entries(min(ck + 1, c_end - 1));  // (the last iteration re-reads its own chunk: keeps p_* = this chunk)
         if constexpr (RM) rm_use();       // row pointer of chunk ck + 1 (its list entry was requested a chunk ago)
         // (one call site: two copies of the MFMA phase made hipcc double the accumulators and spill)
-        Mfma96<T, W2_MI>::template slab<RM>(cur, cur + W2_A_BYTES, wm * 32 * W2_MI, wn * 96, lane, acc, [&](int kk) {
+        Mfma96<T, W2_MI>::template slab<RM, false>(cur, cur + W2_A_BYTES, wm * 32 * W2_MI, wn * 96, lane, acc, [&](int kk) {
             if (more && kk < 2) dma3(ck + 1, buf ^ 1, kk * (W2_PIECES / 2));  // >= half a phase to land
             if constexpr (RM) {
                 if (kk == 2) rm_row(min(ck + 2, c_end - 1));  // the row list entry of the chunk after next (an L2 hit by then)
@@ -626,6 +626,116 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
 }
 
 // ------------------------------------------------------------------------------------------------
+// wgrad2d_kernel: wgrad2_kernel's geometry (192 x 384 tiles, 8 waves as 2 x 4, wave tile 96 x 96, split-K over the batch,
+// both matrices in one launch: 32 tiles x 8 splits = one workgroup per CU at 384 -> 3072) with a DENSE left operand: the ReLU
+// SAE's contractions dW_dT = hidden^T g and dW_e = dpre^T x (wsae_relu.hip), where hidden and dpre are bf16 [B][H] matrices
+// read row-major like the right operands.  Per 64-row chunk a wave DMA-gathers its 8 batch rows of three 64-feature blocks
+// (left) and six 64-column blocks (right); both fragment kinds are transposed LDS reads.  No code, no scatter: ONE barrier per
+// chunk.  (The 256 x 256 tiles of gemm256x_kernel put a quarter of their MFMA work outside a 384-wide matrix and fill 192 of
+// 256 CUs: 2 x 64 us against this launch's single pass.)  B must be a multiple of 64 (no zero padding of a dense operand).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(W2_THREADS)
+wgrad2d_kernel(const bf16_t* __restrict__ hid, const bf16_t* __restrict__ dpre, const bf16_t* __restrict__ xb,
+               const bf16_t* __restrict__ gb, int B, int H, int D, int nsplit, int ntm, int ntn, float* __restrict__ out,
+               int nslots) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 64, EPC = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int split = blockIdx.x % nsplit;
+    int tile = blockIdx.x / nsplit;
+    const int which = tile / (ntm * ntn);  // 0: dW_dT (hidden, g)   1: dW_e (dpre, x)
+    tile -= which * ntm * ntn;
+    const int tm = tile / ntn, tn = tile % ntn;
+    const int f0 = tm * W2_M, d0 = tn * W2_N;
+    const bf16_t* Am = which == 0 ? hid : dpre;  // [B][H]
+    const bf16_t* Bm = which == 0 ? gb : xb;     // [B][D]
+    const int nchunks = B / KT;
+    const int per = (nchunks + nsplit - 1) / nsplit;
+    const int c_begin = split * per, c_end = min(nchunks, c_begin + per);
+
+    f32x16 acc[W2_MI][3];
+#pragma unroll
+    for (int i = 0; i < W2_MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int dma_r = lane >> 3, dma_s = lane & 7;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int rm_c = (dma_s ^ rm_swz(wave * 8 + dma_r)) * EPC;  // source chunk of this lane's LDS slot
+    // chunk ck into stage `stage`: this wave's 8 batch rows x (3 feature blocks | 6 column blocks); part = 0 / 1 / 2 issues
+    // (A blocks) / (B blocks 0-2) / (B blocks 3-5) so that the pieces can be spread over the MFMA phase
+    auto dma = [&](int ck, int stage, int part) {
+        const int64_t b = (int64_t)ck * KT + wave * 8 + dma_r;
+        const uint32_t base = smem_lds + stage * W2_STAGE;
+        if (part == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                glds16(Am + b * H + min(f0 + j * 64 + rm_c, H - EPC), base + j * 8192 + wave * 1024);
+        } else {
+#pragma unroll
+            for (int j = 3 * (part - 1); j < 3 * part; ++j)
+                glds16(Bm + b * D + min(d0 + j * 64 + rm_c, D - EPC), base + W2_A_BYTES + j * 8192 + wave * 1024);
+        }
+    };
+    if (c_begin < c_end) {
+        dma(c_begin, 0, 0); dma(c_begin, 0, 1); dma(c_begin, 0, 2);
+        dma_wait();
+        __syncthreads();
+    }
+    for (int ck = c_begin; ck < c_end; ++ck) {
+        const int buf = (ck - c_begin) & 1;
+        char* cur = smem + buf * W2_STAGE;
+        const bool more = ck + 1 < c_end;
+        Mfma96<bf16_t, W2_MI>::template slab<true, true>(cur, cur + W2_A_BYTES, wm * 32 * W2_MI, wn * 96, lane, acc, [&](int kk) {
+            if (more) dma(ck + 1, buf ^ 1, kk);  // (kk = 0, 1, 2: the three parts)
+        });
+        dma_wait();       // issued during this chunk's MFMA phase: landed
+        __syncthreads();  // ... for every wave; and everybody is done reading `cur` (the chunk after next lands there)
+    }
+
+    const int64_t rstr = (int64_t)nslots * D;
+    float* dst = out + (which == 0 ? (int64_t)H * rstr : 0) + (int64_t)split * D;
+    const int col = lane & 31, rq = lane >> 5;
+    if (f0 + W2_M <= H && d0 + W2_N <= D) {  // interior tiles: 16-byte stores through an LDS patch (as wgrad2_kernel)
+        constexpr int PSW = 100;
+        float* patch = (float*)smem + wave * 32 * PSW;
+        float* drow = dst + (int64_t)(f0 + wm * 32 * W2_MI) * rstr + d0 + wn * 96;
+#pragma unroll
+        for (int mi = 0; mi < W2_MI; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * rq) * PSW + ni * 32 + col] = acc[mi][ni][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int idx = lane + 64 * i;
+                const int row = idx / 24, c4 = idx - row * 24;
+                const float4 v = *(const float4*)(patch + row * PSW + c4 * 4);
+                *(float4*)(drow + (int64_t)(mi * 32 + row) * rstr + c4 * 4) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < W2_MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) {
+                const int d = d0 + wn * 96 + ni * 32 + col;
+                if (d >= D) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = f0 + wm * 32 * W2_MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+                    if (f < H) dst[(int64_t)f * rstr + d] = acc[mi][ni][r];
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // grad_finish_kernel: everything between the split-K contraction and the optimizer (or the data-parallel exchange), in
 // ONE launch of three kinds of blocks (they share nothing, so they share the launch instead of queueing behind each
 // other's tails):
@@ -675,7 +785,7 @@ grad_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ db
                    const float* __restrict__ bpre, OT* __restrict__ out, GfOut o, int H, int D, float* __restrict__ part_sq,
                    int nrb, int row0, int nrows, int slab_row0, const TW* __restrict__ W, float* __restrict__ part,
                    int nblk_h, const float* __restrict__ part_dbd, int n_dec, float* __restrict__ dbd2,
-                   unsigned long long* __restrict__ ticket, int do_bias, const float* __restrict__ fired_src) {
+                   unsigned long long* __restrict__ ticket, int do_bias, const float* __restrict__ fired_src, int with_dbe) {
     __shared__ float red[8];
     __shared__ float e_s[DBPRE_ROWS];
     __shared__ __attribute__((aligned(16))) float p_s[1024];  // row-part sums of a db_pre block (D <= 512: parts x D <= 1024)
@@ -702,7 +812,7 @@ grad_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ db
             const int nr = min(2, min(rpw - q, row0 + nrows - r0));
             // db_e[h] = sum over splits, in split order (the db_pre blocks below use the same order)
             float be[2] = {0.f, 0.f};
-            if (r0 < H) {  // (only dW_e rows have one)
+            if (with_dbe && r0 < H) {  // (only dW_e rows have one; the dense ReLU contraction leaves none: with_dbe = 0)
                 const int j = lane / NS, sp = lane % NS;
                 const float v = (j < nr && sp < nsplit && r0 + j < H) ? dbe_slab[(int64_t)sp * H + r0 + j] : 0.f;
 #pragma unroll
@@ -1004,7 +1114,7 @@ static void launch_grad_finish(wsae_ctx* ctx, const WgPlan& p, hipStream_t st, c
     unsigned long long* ticket = (unsigned long long*)(ctx->counters + 16 + 4 * TICKET_WORDS);
     const int grid = nrb + (do_bias ? nblk + DBD_L1 : 0);
 #define GF_ARGS ctx->wg_slabs, ctx->dbe_slab, p.nsplit, bpre, out, o, H, D, ctx->part_sq, nrb, row0, nrows, slab_row0, W, \
-                ctx->dbpre_part, nblk, ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2, ticket, do_bias, fired_src
+                ctx->dbpre_part, nblk, ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2, ticket, do_bias, fired_src, 1
     if (p.nslots == WSAE_WGRAD_MAX_SPLIT) grad_finish_kernel<TW, FOLD, OT, WSAE_WGRAD_MAX_SPLIT><<<grid, 256, 0, st>>>(GF_ARGS);
     else grad_finish_kernel<TW, FOLD, OT, 2 * WSAE_WGRAD_MAX_SPLIT><<<grid, 256, 0, st>>>(GF_ARGS);
 #undef GF_ARGS
@@ -1081,4 +1191,26 @@ extern "C" int wsae_weight_grads_wire(wsae_ctx* ctx, const float* params, const 
                  "wsae_weight_grads_wire: part must be WSAE_PART_ALL, _DECODER or _ENCODER");
     WSAE_REQUIRE(ctx && (part == WSAE_PART_DECODER || ctx->fired), "wsae_weight_grads_wire: set the fired buffer first (wsae_ctx_set_fired)");
     return weight_grads_impl(ctx, params, x, x_dtype, rows, vals, idx, dpre, B, part, nullptr, wire, wire_dtype, (hipStream_t)stream);
+}
+
+// The ReLU SAE's two weight-gradient contractions (wsae_relu.hip, row-major-GEMM flow) on wgrad2d_kernel + the slab
+// reduction of grad_finish_kernel (matrix rows and their norm partials only: this module's bias gradients come from its own
+// column sums and it has no pre-bias).  hid / dpre: bf16 [B][H]; xb / gb: bf16 [B][D]; grads: the fp32 pack.  Returns the
+// number of norm partials left in ctx->part_sq (slots [0, n)), or 0 when the shape is not served (the caller keeps its GEMMs).
+int wsae_internal_relu_wgrad(wsae_ctx* ctx, const void* hid, const void* dpre, const void* xb, const void* gb, int B, float* grads,
+                             hipStream_t st) {
+    const int H = ctx->H, D = ctx->D;
+    if (ctx->prec != WSAE_PREC_BF16 || D <= 256 || D % 8 || H % 8 || B % 64 || B < 64) return 0;
+    const int ntm = ceil_div(H, W2_M), ntn = ceil_div(D, W2_N);
+    const int nchunks = B / 64;
+    const int nsplit = pick_nsplit(ctx, ntm * ntn * 2, nchunks, 0, WSAE_WGRAD_MAX_SPLIT);
+    wgrad2d_kernel<<<ntm * ntn * 2 * nsplit, W2_THREADS, 2 * W2_STAGE, st>>>((const bf16_t*)hid, (const bf16_t*)dpre, (const bf16_t*)xb,
+                                                                             (const bf16_t*)gb, B, H, D, nsplit, ntm, ntn, ctx->wg_slabs,
+                                                                             WSAE_WGRAD_MAX_SPLIT);
+    const GfOut o = {ctx->off[0], ctx->off[1], ctx->off[2], ctx->off[3], ctx->off[4], 0};
+    const int nrb = (int)min((int64_t)WSAE_MAX_PARTIALS - 2, ceil_div64(2 * (int64_t)H, 8));
+    grad_finish_kernel<bf16_t, false, float, WSAE_WGRAD_MAX_SPLIT><<<nrb, 256, 0, st>>>(
+        ctx->wg_slabs, ctx->dbe_slab, nsplit, nullptr, grads, o, H, D, ctx->part_sq, nrb, 0, 2 * H, 0, (const bf16_t*)nullptr,
+        ctx->dbpre_part, 0, ctx->part_dbd, 0, ctx->dbd2, (unsigned long long*)(ctx->counters + 16 + 4 * TICKET_WORDS), 0, nullptr, 0);
+    return nrb;
 }
