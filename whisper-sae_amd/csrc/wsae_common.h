@@ -274,8 +274,9 @@ struct GxEpi {
     float* c;              // PLAIN: fp32 C [M][ldc] (+ z * cz);  RELU: optional fp32 copy of hidden (nullable)
     int64_t ldc, cz;
     bf16_t* out16;         // RELU: hidden bf16 [M][ld16];  DPRE: dpre bf16 [M][ld16]
-    uint64_t* bits;        // RELU (out) / DPRE (in): [M][ldbits] words, one per (row, 64-column span of a wave tile): bit 16 c + j =
-                           // (hidden > 0) at column 64 w + 4 j + c - the dpre mask at 1/16 of the bytes of re-reading bf16 hidden
+    uint64_t* bits;        // RELU (out) / DPRE (in): [N / 64][ldbits] words (column-major: ldbits >= M rows per word column), one
+                           // per (row, 64-column span of a wave tile): bit 16 c + j = (hidden > 0) at column 64 w + 4 j + c - the
+                           // dpre mask at 1/16 of the bytes of re-reading bf16 hidden
     int64_t ldbits;
     int64_t ld16;
     const float* colw;     // RELU / DPRE: per-column weights of the L1 term (nullable = 1)

@@ -155,9 +155,9 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
         uint64_t mw0 = 0, mw1 = 0;
         if constexpr (EPI == GX_EPI_DPRE) {
             const int ra = min(m0 + wm * 128 + lane, M - 1), rb = min(m0 + wm * 128 + 64 + lane, M - 1);
-            if (n0 + wn * 64 < N) {
-                mw0 = e.bits[(int64_t)ra * e.ldbits + widx];
-                mw1 = e.bits[(int64_t)rb * e.ldbits + widx];
+            if (n0 + wn * 64 < N) {  // (column-major words: a wave's 128 rows of one word column are 1 KB contiguous)
+                mw0 = e.bits[widx * e.ldbits + ra];
+                mw1 = e.bits[widx * e.ldbits + rb];
             }
         }
 #pragma unroll
@@ -168,6 +168,7 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
                 for (int r = 0; r < 16; ++r)
                     patch[((r & 3) + 8 * (r >> 2) + 4 * rq) * PS + ni * 32 + col] = acc[mi][ni][r];
             __builtin_amdgcn_wave_barrier();
+            unsigned long long keep = 0;  // RELU: lane (pr, j = i) keeps the activity word of row pr + 4 i; ONE store per 32 rows
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int rl = pr + 4 * i;
@@ -192,12 +193,17 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
                     // matrix vote 0); the first lane of a row's 16 writes the row's word.  (bf16 keeps fp32's exponent range: a
                     // positive hidden value stays positive when it is rounded, so these are also the bits of bf16(hidden) > 0.)
                     {
+                        // (32-bit field extracts: the 64-bit vector shifts of the obvious form cost this epilogue 14 us per launch)
                         const unsigned long long bx = __ballot(ok && v.x > 0.f), by = __ballot(ok && v.y > 0.f);
                         const unsigned long long bz = __ballot(ok && v.z > 0.f), bw = __ballot(ok && v.w > 0.f);
-                        const int sh = 16 * pr;
-                        const unsigned long long word = ((bx >> sh) & 0xFFFFull) | (((by >> sh) & 0xFFFFull) << 16) |
-                                                        (((bz >> sh) & 0xFFFFull) << 32) | (((bw >> sh) & 0xFFFFull) << 48);
-                        if ((lane & 15) == 0 && m < M && n0 + wn * 64 < N) e.bits[(int64_t)m * e.ldbits + widx] = word;
+                        const bool uh = pr >= 2;         // rows 2, 3 of the instruction sit in the ballots' upper words
+                        const int sh = 16 * (pr & 1);
+                        const uint32_t fx = __builtin_amdgcn_ubfe(uh ? (uint32_t)(bx >> 32) : (uint32_t)bx, sh, 16);
+                        const uint32_t fy = __builtin_amdgcn_ubfe(uh ? (uint32_t)(by >> 32) : (uint32_t)by, sh, 16);
+                        const uint32_t fz = __builtin_amdgcn_ubfe(uh ? (uint32_t)(bz >> 32) : (uint32_t)bz, sh, 16);
+                        const uint32_t fw = __builtin_amdgcn_ubfe(uh ? (uint32_t)(bw >> 32) : (uint32_t)bw, sh, 16);
+                        const unsigned long long word = (unsigned long long)(fx | (fy << 16)) | ((unsigned long long)(fz | (fw << 16)) << 32);
+                        if ((lane & 15) == i) keep = word;
                     }
                 } else {
                     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -217,6 +223,12 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
                     }
                     csum.x += d.x; csum.y += d.y; csum.z += d.z; csum.w += d.w;
                 }
+            }
+            if constexpr (EPI == GX_EPI_RELU) {
+                // rows pr + 4 j (j = lane & 15 < 8) of this 32-row group: 32 consecutive rows of one word column = 256 contiguous bytes
+                const int j = lane & 15;
+                const int m = m0 + wm * 128 + mi * 32 + pr + 4 * j;
+                if (j < 8 && m < M && n0 + wn * 64 < N) e.bits[widx * e.ldbits + m] = keep;
             }
             __builtin_amdgcn_wave_barrier();
         }

@@ -231,6 +231,15 @@ __device__ __forceinline__ void glds16(const void* src, uint32_t lds_byte) {
                  : "v"(src), "s"(lds_addr)
                  : "memory");
 }
+// the same with the non-temporal policy: for operands every byte of which ONE workgroup reads once (a streamed [B, H] matrix)
+__device__ __forceinline__ void glds16_nt(const void* src, uint32_t lds_byte) {
+    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(lds_byte);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_addr)
+                 : "memory");
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // wave tile (32 MI) x 96 = MI x 3 MFMA tiles: MI = 3 is 144 accumulator VGPRs and 6 fragment reads

@@ -400,9 +400,12 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ p
 // rows 8 loads at a time, the four part sums meet in LDS in fixed order.  Blocks [0, nb1) serve (part1, N1), the rest (part2, N2).
 __global__ void __launch_bounds__(256)
 colsum2_kernel(const float* __restrict__ part1, int nrows1, int N1, float* __restrict__ out1, int nb1,
-               const float* __restrict__ part2, int nrows2, int N2, float* __restrict__ out2) {
+               const float* __restrict__ part2, int nrows2, int N2, float* __restrict__ out2, float* __restrict__ zero_n2) {
     __shared__ float s[4][64];
     const bool second = (int)blockIdx.x >= nb1;
+    // (no pre-bias in this module: its gradient slot, N2 values, stays exactly 0 - written here instead of by a fill launch)
+    if (second && zero_n2 && threadIdx.x < 64 && ((int)blockIdx.x - nb1) * 64 + (int)threadIdx.x < N2)
+        zero_n2[((int)blockIdx.x - nb1) * 64 + threadIdx.x] = 0.f;
     const float* part = second ? part2 : part1;
     const int nrows = second ? nrows2 : nrows1, N = second ? N2 : N1;
     float* out = second ? out2 : out1;
@@ -561,7 +564,7 @@ int forward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     e1.out16 = (bf16_t*)ws.hid; e1.ld16 = H;
     e1.colw = ctx->relu_l1w;
     e1.part = ws.part; e1.nslots = ws.nblk;
-    e1.bits = (uint64_t*)ws.dpreT; e1.ldbits = ceil_div(H, 64);  // (the transposed-dpre buffer of the general path is free in this flow)
+    e1.bits = (uint64_t*)ws.dpreT; e1.ldbits = ldT;  // (the transposed-dpre buffer of the general path is free in this flow)
     WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 0, GX_EPI_RELU, ctx->xb, D, ctx->We_bf16, D, B, H, D, 1, e1, st),
                  "wsae_relu_forward: encoder GEMM rejected B %d, D %d, H %d", B, D, H);
     GxEpi e2 = {};
@@ -601,7 +604,7 @@ int backward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
     bf16_t* dpre = (bf16_t*)ws.hidT;  // [B][H] (the transposed-hidden buffer of the general path is free in this flow)
     GxEpi e3 = {};
     e3.out16 = dpre; e3.ld16 = H;
-    e3.bits = (uint64_t*)ws.dpreT; e3.ldbits = ceil_div(H, 64);  // the activity bits the forward's epilogue left: 1/16 of re-reading hidden
+    e3.bits = (uint64_t*)ws.dpreT; e3.ldbits = ldT;  // the activity bits the forward's epilogue left: 1/16 of re-reading hidden
     e3.colw = ctx->relu_l1w;
     e3.l1 = weight / ((float)B * (float)H);
     e3.colpart = ws.colpart;
@@ -623,12 +626,10 @@ int backward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
                      "wsae_relu_backward: dW_d contraction rejected B %d (split %d)", B, nz);
         nsq = 1022;  // (blocks = norm partial slots; + 1 for the biases, WSAE_MAX_PARTIALS = 1024)
         slab_sum8_kernel<<<nsq, 256, 0, st>>>(ctx->wg_slabs, slab_stride, nz, slab_stride / 4, grads, grads + ctx->off[4], D, ctx->part_sq);
-    } else {
-        WSAE_HIP_CHECK(hipMemsetAsync(grads + ctx->off[4], 0, (size_t)D * sizeof(float), st));  // no pre-bias in this module: its gradient stays exactly 0
     }
     const int nb1 = ceil_div(H, 64);
     colsum2_kernel<<<nb1 + ceil_div(D, 64), 256, 0, st>>>(ws.colpart, B / 128, H, grads + ctx->off[2], nb1, ctx->part_dbd,
-                                                          ceil_div(B, 64), D, grads + ctx->off[3]);
+                                                          ceil_div(B, 64), D, grads + ctx->off[3], grads + ctx->off[4]);
     bias_sq_kernel<<<1, 256, 0, st>>>(grads + ctx->off[2], H, grads + ctx->off[3], D, ctx->part_sq + nsq);
     WSAE_LAUNCH_CHECK();
     ctx->n_sq_parts = nsq + 1;  // wsae_adamw_step(norm_from_wgrad = 1) sums these: no separate norm pass

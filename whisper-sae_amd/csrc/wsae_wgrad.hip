@@ -672,7 +672,7 @@ wgrad2d_kernel(const bf16_t* __restrict__ hid, const bf16_t* __restrict__ dpre, 
         if (part == 0) {
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                glds16(Am + b * H + min(f0 + j * 64 + rm_c, H - EPC), base + j * 8192 + wave * 1024);
+                glds16_nt(Am + b * H + min(f0 + j * 64 + rm_c, H - EPC), base + j * 8192 + wave * 1024);  // streamed once: nt
         } else {
 #pragma unroll
             for (int j = 3 * (part - 1); j < 3 * part; ++j)
