@@ -284,9 +284,13 @@ struct GxEpi {
     float* part;           // RELU: part[tile] = sum relu * w, part[nslots + tile] = count(relu > 0)
     int nslots;
     float* colpart;        // DPRE: colpart[(m0 / 128 + wm)][n] = column sums of dpre over 128 rows
+    const float* rscale;   // fp8 operands: C = rscale[m] * cscale[n] * acc (+ bias) - the per-row dequantisation scales (nullable)
+    const float* cscale;
+    float* rowmax;         // RELU (optional): [N / 64][ldbits] maxima of relu over each row's 64-column span (the next GEMM's
+                           // per-row quantisation scale comes from them without another pass over hidden)
 };
 bool wsae_internal_gemm256x(wsae_ctx* c, int a_rm, int b_rm, int epi, const void* A, int64_t lda, const void* Bm, int64_t ldb,
-                            int M, int N, int K, int nsplit, const GxEpi& e, hipStream_t st);
+                            int M, int N, int K, int nsplit, const GxEpi& e, hipStream_t st, int fp8 = 0);
 // internal (wsae_wgrad.hip): the ReLU SAE's two contractions on the 192 x 384 geometry + slab reduction; 0 = shape not served
 int wsae_internal_relu_wgrad(wsae_ctx* ctx, const void* hid, const void* dpre, const void* xb, const void* gb, int B, float* grads,
                              hipStream_t st);

@@ -26,12 +26,19 @@ __device__ __forceinline__ int gx_rm_swz(int r) { return (((r >> 1) & 1) << 2) |
 
 typedef __attribute__((address_space(3))) bf16x4 gx_lds_bf16x4;
 
-template <bool ARM, bool BRM, int EPI>
+// FP8 (NT/NT only): one-byte OCP e4m3 operands - a 128-byte image row holds 128 K elements - multiplied by
+// v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 0x7F): twice the bf16 form's flops per cycle; the per-row
+// dequantisation scales of both operands are applied to the accumulator in the epilogue.  Lane l (row l & 31, half l >> 5)
+// supplies the 32 bytes k = 32 (l >> 5) .. + 31 of its row for each 64-deep step (profiles/tools/probe_mxfp8.hip: with unit
+// scales any assignment of a half's 32 k to the lane's bytes is equivalent as long as both operands use the same one).
+template <bool ARM, bool BRM, int EPI, bool FP8 = false>
 __global__ void __launch_bounds__(512)
 gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm, int64_t ldb, int M, int N, int Kr,
                 int ntn, int ntiles_mn, int nsplit, GxEpi e) {
+    static_assert(!FP8 || (!ARM && !BRM), "fp8 operands are K-contiguous");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KT = 64, EPC = 8;
+    constexpr int ESZ = FP8 ? 1 : 2;                 // bytes per operand element (A / Bm / lda / ldb / Kr count ELEMENTS)
+    constexpr int KT = 128 / ESZ, EPC = 16 / ESZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int nk = Kr / KT;
@@ -60,8 +67,10 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
             } else {
                 const int row = pi * 8 + dma_r;                        // operand row inside the 256-row tile
                 const int c = dma_s ^ ((row >> 1) & 7);
-                if (isA) src = A + (int64_t)min(m0 + row, M - 1) * lda + k0 + c * EPC;
-                else src = Bm + (int64_t)min(n0 + row, N - 1) * ldb + k0 + c * EPC;
+                const char* base8 = (const char*)(isA ? A : Bm);
+                const int64_t el = isA ? (int64_t)min(m0 + row, M - 1) * lda + k0 + c * EPC
+                                       : (int64_t)min(n0 + row, N - 1) * ldb + k0 + c * EPC;
+                src = (const bf16_t*)(base8 + el * ESZ);
             }
             glds16(src, base + piece * 1024);
         }
@@ -119,6 +128,38 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
             else dma(m_of(nt), n_of(nt), k_of(nt), st ^ 1);
             const char* As = smem + (st ? GX_STAGE1 : 0);
             const char* Bs = As + 256 * SWZ_ROW_BYTES;
+            if constexpr (FP8) {
+                typedef int v8i __attribute__((ext_vector_type(8)));
+                typedef int v4i __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {  // two 64-deep steps per 128-byte row
+                    const int c0 = 4 * s2 + 2 * h;
+                    const int o0 = (c0 ^ sw) << 4, o1 = ((c0 + 1) ^ sw) << 4;
+                    v8i b[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const v4i lo = *(const v4i*)(Bs + b_nt + i * 32 * SWZ_ROW_BYTES + o0);
+                        const v4i hi = *(const v4i*)(Bs + b_nt + i * 32 * SWZ_ROW_BYTES + o1);
+                        b[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh) {  // (the A fragments two at a time: 8 registers each)
+                        v8i a[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const v4i lo = *(const v4i*)(As + a_nt + (2 * mh + i) * 32 * SWZ_ROW_BYTES + o0);
+                            const v4i hi = *(const v4i*)(As + a_nt + (2 * mh + i) * 32 * SWZ_ROW_BYTES + o1);
+                            a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni)
+                                acc[2 * mh + i][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[ni], acc[2 * mh + i][ni], 0, 0, 0,
+                                                                                                      0x7F7F7F7F, 0, 0x7F7F7F7F);
+                    }
+                }
+            } else
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int co = ((kk * 2 + h) ^ sw) << 4;
@@ -148,6 +189,10 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
         float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(1.f, 1.f, 1.f, 1.f);
         if (EPI != GX_EPI_DPRE && e.bias && z == 0 && col_ok) bv4 = *(const float4*)(e.bias + ncol);
         if (EPI != GX_EPI_PLAIN && e.colw && col_ok) w4 = *(const float4*)(e.colw + ncol);
+        float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);  // fp8 operands: column (Bt row) dequantisation scales
+        if constexpr (FP8) {
+            if (col_ok) cs4 = *(const float4*)(e.cscale + ncol);
+        }
         float s_l1 = 0.f, s_cnt = 0.f;                 // RELU partials
         float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);  // DPRE column sums (this lane's rows)
         const int64_t widx = (n0 + wn * 64) >> 6;        // this wave's word of a row's activity bits
@@ -169,12 +214,17 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
                     patch[((r & 3) + 8 * (r >> 2) + 4 * rq) * PS + ni * 32 + col] = acc[mi][ni][r];
             __builtin_amdgcn_wave_barrier();
             unsigned long long keep = 0;  // RELU: lane (pr, j = i) keeps the activity word of row pr + 4 i; ONE store per 32 rows
+            float keepmax = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int rl = pr + 4 * i;
                 const int m = m0 + wm * 128 + mi * 32 + rl;
                 float4 v = *(const float4*)(patch + rl * PS + pc);
                 const bool ok = m < M && col_ok;
+                if constexpr (FP8) {
+                    const float rs = e.rscale[min(m, M - 1)];
+                    v.x *= rs * cs4.x; v.y *= rs * cs4.y; v.z *= rs * cs4.z; v.w *= rs * cs4.w;
+                }
                 if constexpr (EPI == GX_EPI_PLAIN) {
                     v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
                     if (ok) *(float4*)(e.c + (int64_t)z * e.cz + (int64_t)m * e.ldc + ncol) = v;
@@ -205,6 +255,16 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
                         const unsigned long long word = (unsigned long long)(fx | (fy << 16)) | ((unsigned long long)(fz | (fw << 16)) << 32);
                         if ((lane & 15) == i) keep = word;
                     }
+                    if constexpr (FP8) {  // maximum of this row's 64-column span (relu >= 0): the 16 lanes of the row meet by lane exchanges
+                        // (of the bf16-ROUNDED values: what the quantisation pass and the oracle's "fp8" mode take the maximum of)
+                        float mx = fmaxf(fmaxf((float)(bf16_t)v.x, (float)(bf16_t)v.y), fmaxf((float)(bf16_t)v.z, (float)(bf16_t)v.w));
+                        mx = ok ? mx : 0.f;
+                        mx = fmaxf(mx, __uint_as_float(lane_xor_u32<1>(__float_as_uint(mx), lane)));
+                        mx = fmaxf(mx, __uint_as_float(lane_xor_u32<2>(__float_as_uint(mx), lane)));
+                        mx = fmaxf(mx, __uint_as_float(lane_xor_u32<4>(__float_as_uint(mx), lane)));
+                        mx = fmaxf(mx, __uint_as_float(lane_xor_u32<8>(__float_as_uint(mx), lane)));
+                        if ((lane & 15) == i) keepmax = mx;
+                    }
                 } else {
                     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
                     // this row's word sits in lane (32 mi + 4 i + pr) & 63 of mw0 (rows 0..63 of the wave tile) or mw1
@@ -228,7 +288,10 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
                 // rows pr + 4 j (j = lane & 15 < 8) of this 32-row group: 32 consecutive rows of one word column = 256 contiguous bytes
                 const int j = lane & 15;
                 const int m = m0 + wm * 128 + mi * 32 + pr + 4 * j;
-                if (j < 8 && m < M && n0 + wn * 64 < N) e.bits[widx * e.ldbits + m] = keep;
+                if (j < 8 && m < M && n0 + wn * 64 < N) {
+                    e.bits[widx * e.ldbits + m] = keep;
+                    if constexpr (FP8) e.rowmax[widx * e.ldbits + m] = keepmax;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -265,8 +328,11 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
 // Shape rules: M, N multiples of 8 (N of 4 for fp32 C), Kr = K / nsplit a multiple of 128 (an even number of 64-deep slabs),
 // leading dimensions multiples of 8 elements.  Returns false when the shape does not qualify (the caller keeps its old path).
 bool wsae_internal_gemm256x(wsae_ctx* c, int a_rm, int b_rm, int epi, const void* A, int64_t lda, const void* Bm, int64_t ldb,
-                            int M, int N, int K, int nsplit, const GxEpi& e, hipStream_t st) {
-    if (M < 256 || N < 128 || M % 8 || N % 8 || nsplit < 1 || K % nsplit || (K / nsplit) % 128 || lda % 8 || ldb % 8) return false;
+                            int M, int N, int K, int nsplit, const GxEpi& e, hipStream_t st, int fp8) {
+    // (an even number of K slabs per range: 64 elements per slab in bf16, 128 in fp8; 16-byte aligned rows)
+    const int slab2 = fp8 ? 256 : 128, al = fp8 ? 16 : 8;
+    if (M < 256 || N < 128 || M % 8 || N % 8 || nsplit < 1 || K % nsplit || (K / nsplit) % slab2 || lda % al || ldb % al) return false;
+    if (fp8 && (a_rm || b_rm || epi == GX_EPI_DPRE || !e.rscale || !e.cscale || (epi == GX_EPI_RELU && !e.rowmax))) return false;
     if (epi != GX_EPI_PLAIN && nsplit != 1) return false;
     const int ntn = ceil_div(N, 256), ntiles_mn = ntn * ceil_div(M, 256);
     if (epi == GX_EPI_RELU && ntiles_mn > e.nslots) return false;
@@ -274,6 +340,11 @@ bool wsae_internal_gemm256x(wsae_ctx* c, int a_rm, int b_rm, int epi, const void
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* b = (const bf16_t*)Bm;
 #define GX_LAUNCH(AR, BR, EP) gemm256x_kernel<AR, BR, EP><<<grid, 512, GX_LDS, st>>>(a, lda, b, ldb, M, N, K / nsplit, ntn, ntiles_mn, nsplit, e)
+    if (fp8) {
+        if (epi == GX_EPI_RELU) gemm256x_kernel<false, false, GX_EPI_RELU, true><<<grid, 512, GX_LDS, st>>>(a, lda, b, ldb, M, N, K / nsplit, ntn, ntiles_mn, nsplit, e);
+        else gemm256x_kernel<false, false, GX_EPI_PLAIN, true><<<grid, 512, GX_LDS, st>>>(a, lda, b, ldb, M, N, K / nsplit, ntn, ntiles_mn, nsplit, e);
+        return true;
+    }
     if (!a_rm && !b_rm && epi == GX_EPI_RELU) GX_LAUNCH(false, false, GX_EPI_RELU);
     else if (!a_rm && !b_rm && epi == GX_EPI_DPRE) GX_LAUNCH(false, false, GX_EPI_DPRE);
     else if (!a_rm && b_rm && epi == GX_EPI_PLAIN) GX_LAUNCH(false, true, GX_EPI_PLAIN);

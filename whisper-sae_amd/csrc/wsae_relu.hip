@@ -542,7 +542,36 @@ static void quant_rows(hipStream_t st, const void* src, int dtype, const int32_t
 // fp32 pre, fp32 hidden, fp32 dh and two transposed bf16 copies out and back in on the general path below (1.2 GB at
 // 384 -> 3072 / B = 16384).
 bool x_flow_ok(const wsae_ctx* c, int B) {
-    return c->prec == WSAE_PREC_BF16 && !c->relu_fp8 && B >= 256 && B % 128 == 0 && c->D % 128 == 0 && c->H % 256 == 0 && 2 * c->D <= c->H;
+    const bool base = c->prec == WSAE_PREC_BF16 && B >= 256 && B % 128 == 0 && c->D % 128 == 0 && c->H % 256 == 0 && 2 * c->D <= c->H;
+    // precision = "fp8": the two forward GEMMs walk 128-element slabs in pairs (D % 256, (H / 2) % 256); other fp8 shapes keep the
+    // general path below
+    return base && (!c->relu_fp8 || (c->D % 256 == 0 && c->H % 512 == 0));
+}
+
+// bf16 hidden [R][C] -> e4m3 with one scale per row, the row's maximum taken from the [C / 64][ld] partial maxima the encoder
+// GEMM's epilogue left (one pass over hidden instead of two).  One block per row.
+__global__ void __launch_bounds__(256)
+quant_hidden_kernel(const bf16_t* __restrict__ src, const float* __restrict__ pmax, int64_t ld, int R, int C, uint8_t* __restrict__ q,
+                    float* __restrict__ scale) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    float amax = 0.f;
+    for (int w = threadIdx.x; w < C / 64; w += 256) amax = fmaxf(amax, pmax[(int64_t)w * ld + r]);
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float inv = amax > 0.f ? 448.f / amax : 1.f;
+    if (threadIdx.x == 0) scale[r] = amax > 0.f ? amax / 448.f : 1.f;
+    for (int c = threadIdx.x * 8; c < C; c += 2048) {
+        const bf16x8 a = *(const bf16x8*)(src + (int64_t)r * C + c);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)a[0] * inv, (float)a[1] * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)a[2] * inv, (float)a[3] * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)a[4] * inv, (float)a[5] * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)a[6] * inv, (float)a[7] * inv, hi, true);
+        *(int2*)(q + (int64_t)r * C + c) = make_int2(lo, hi);
+    }
 }
 
 int x_split(int B) {  // split-K over the batch: ranges of whole 128-row groups, at least 512 rows each
@@ -558,6 +587,11 @@ int forward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     const ReluWs ws = host_ws(ctx);
     int rc = wsae_internal_stage_rows(ctx, params, x, x_dtype, rows, B, st);  // xb = bf16(x) [B][D] (the contractions read it row-major)
     if (rc) return rc;
+    // precision = "fp8" (wsae_ctx_set_relu_fp8; BASELINE.json configs[4]): the two forward GEMMs on OCP e4m3 operands - x and
+    // bf16(hidden) quantised per batch row, the bf16 shadows of W_e per feature row and of W_d per output row - through the
+    // block-scaled MFMA with unit block scales (twice the bf16 rate); the row x column dequantisation scales are applied in the
+    // epilogues.  hidden, loss and the whole backward stay on the bf16 values.  The oracle's "fp8" mode mirrors exactly this.
+    const bool fp8 = ctx->relu_fp8 != 0;
     GxEpi e1 = {};
     e1.bias = params + ctx->off[2];
     e1.c = hidden; e1.ldc = H;
@@ -565,13 +599,31 @@ int forward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     e1.colw = ctx->relu_l1w;
     e1.part = ws.part; e1.nslots = ws.nblk;
     e1.bits = (uint64_t*)ws.dpreT; e1.ldbits = ldT;  // (the transposed-dpre buffer of the general path is free in this flow)
-    WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 0, GX_EPI_RELU, ctx->xb, D, ctx->We_bf16, D, B, H, D, 1, e1, st),
-                 "wsae_relu_forward: encoder GEMM rejected B %d, D %d, H %d", B, D, H);
+    float* rowmax = (float*)((uint64_t*)ws.dpreT + (int64_t)ceil_div(H, 64) * ldT);  // [H / 64][ldT], behind the activity words
+    if (fp8) {
+        quant_rows(st, x, x_dtype, rows, B, D, ws.xq, ws.sx);
+        quant_rows(st, ctx->We_bf16, WSAE_DT_BF16, nullptr, H, D, ws.weq, ws.swe);
+        e1.rscale = ws.sx; e1.cscale = ws.swe; e1.rowmax = rowmax;
+        WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 0, GX_EPI_RELU, ws.xq, D, ws.weq, D, B, H, D, 1, e1, st, 1),
+                     "wsae_relu_forward: fp8 encoder GEMM rejected B %d, D %d, H %d", B, D, H);
+    } else {
+        WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 0, GX_EPI_RELU, ctx->xb, D, ctx->We_bf16, D, B, H, D, 1, e1, st),
+                     "wsae_relu_forward: encoder GEMM rejected B %d, D %d, H %d", B, D, H);
+    }
     GxEpi e2 = {};
     e2.bias = params + ctx->off[3];
     e2.c = ctx->pre; e2.ldc = D; e2.cz = (int64_t)B * D;  // two split-K slabs in the (otherwise unused) pre-activation scratch
-    WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 1, GX_EPI_PLAIN, ws.hid, H, ctx->WdT_bf16, D, B, D, H, 2, e2, st),
-                 "wsae_relu_forward: decoder GEMM rejected B %d, D %d, H %d", B, D, H);
+    if (fp8) {
+        quant_hidden_kernel<<<B, 256, 0, st>>>((const bf16_t*)ws.hid, rowmax, ldT, B, H, ws.hidq, ws.sh);
+        transpose_w_kernel<bf16_t><<<dim3(ceil_div(H, 64), ceil_div(D, 64)), 256, 0, st>>>(ctx->WdT_bf16, (bf16_t*)ws.wd_nt, H, D);
+        quant_rows(st, ws.wd_nt, WSAE_DT_BF16, nullptr, D, H, ws.wdq, ws.swd);
+        e2.rscale = ws.sh; e2.cscale = ws.swd;
+        WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 0, GX_EPI_PLAIN, ws.hidq, H, ws.wdq, H, B, D, H, 2, e2, st, 1),
+                     "wsae_relu_forward: fp8 decoder GEMM rejected B %d, D %d, H %d", B, D, H);
+    } else {
+        WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 1, GX_EPI_PLAIN, ws.hid, H, ctx->WdT_bf16, D, B, D, H, 2, e2, st),
+                     "wsae_relu_forward: decoder GEMM rejected B %d, D %d, H %d", B, D, H);
+    }
     dim3 gr(ceil_div(D, 64), ceil_div(ldT, 64));
     if (x_dtype == WSAE_DT_F32)
         resid_kernel<bf16_t, WSAE_DT_F32, false><<<gr, 256, 0, st>>>(ctx->pre, x, rows, B, D, ldT, 0.f, nullptr, nullptr, nullptr,
