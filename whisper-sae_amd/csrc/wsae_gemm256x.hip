@@ -50,7 +50,9 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
     const int dma_r = lane >> 3, dma_s = lane & 7;
     const int ntiles = ntiles_mn * nsplit;
 
-    // K slab k0 of tile (m0, n0) into stage st: pieces 0..31 = the A operand, 32..63 = the B operand
+    // K slab k0 of tile (m0, n0) into stage st: pieces 0..31 = the A operand, 32..63 = the B operand.  Source address of a
+    // piece = a wave-uniform base (operand + the tile's first row / the slab's first k: an SGPR pair) + a 32-bit per-lane byte
+    // offset inside the tile (row clamps included), so eight pieces cost eight VGPRs, not eight address pairs.
     auto dma = [&](int m0, int n0, int64_t k0, int st) {
         const uint32_t base = smem_lds + (st ? GX_STAGE1 : 0);
 #pragma unroll
@@ -58,21 +60,23 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
             const int piece = wave + 8 * j;  // 0..63
             const int pi = piece & 31;
             const bool isA = j < 4;
-            const bf16_t* src;
+            const char* op = (const char*)(isA ? A : Bm);
+            const int64_t ld = isA ? lda : ldb;
+            const int t0 = isA ? m0 : n0, T = isA ? M : N;
+            const char* sb;
+            uint32_t voff;
             if (isA ? ARM : BRM) {
-                const int krow = (pi & 7) * 8 + dma_r;                 // k row inside the slab
-                const int cbk = (pi >> 3) * 64 + (dma_s ^ gx_rm_swz(krow)) * EPC;  // column inside the 256-wide tile
-                if (isA) src = A + (k0 + krow) * lda + min(m0 + cbk, M - EPC);
-                else src = Bm + (k0 + krow) * ldb + min(n0 + cbk, N - EPC);
+                const int krow = (pi & 7) * 8 + dma_r;                              // k row inside the slab
+                const int cbk = (pi >> 3) * 64 + (dma_s ^ gx_rm_swz(krow)) * EPC;   // column inside the 256-wide tile
+                sb = op + k0 * ld * ESZ;                                            // the slab's first k row
+                voff = (uint32_t)(((int64_t)krow * ld + min(t0 + cbk, T - EPC)) * ESZ);
             } else {
-                const int row = pi * 8 + dma_r;                        // operand row inside the 256-row tile
+                const int row = pi * 8 + dma_r;                                     // operand row inside the 256-row tile
                 const int c = dma_s ^ ((row >> 1) & 7);
-                const char* base8 = (const char*)(isA ? A : Bm);
-                const int64_t el = isA ? (int64_t)min(m0 + row, M - 1) * lda + k0 + c * EPC
-                                       : (int64_t)min(n0 + row, N - 1) * ldb + k0 + c * EPC;
-                src = (const bf16_t*)(base8 + el * ESZ);
+                sb = op + ((int64_t)t0 * ld + k0) * ESZ;                            // the tile's first row at the slab's first k
+                voff = (uint32_t)(((int64_t)(min(t0 + row, T - 1) - t0) * ld + c * EPC) * ESZ);
             }
-            glds16(src, base + piece * 1024);
+            glds16_s(sb, voff, base + piece * 1024);
         }
     };
     auto m_of = [&](int t) { return ((t % ntiles_mn) / ntn) * 256; };
@@ -186,13 +190,9 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
         __syncthreads();
         const int ncol = n0 + wn * 64 + pc;  // this lane's 4 columns
         const bool col_ok = ncol < N;        // (N is a multiple of 4)
-        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (EPI != GX_EPI_DPRE && e.bias && z == 0 && col_ok) bv4 = *(const float4*)(e.bias + ncol);
-        if (EPI != GX_EPI_PLAIN && e.colw && col_ok) w4 = *(const float4*)(e.colw + ncol);
-        float4 cs4 = make_float4(1.f, 1.f, 1.f, 1.f);  // fp8 operands: column (Bt row) dequantisation scales
-        if constexpr (FP8) {
-            if (col_ok) cs4 = *(const float4*)(e.cscale + ncol);
-        }
+        // (the per-column constants - bias, L1 weights, fp8 column scales - are (re)loaded inside the row-group loop below, once per
+        // 32 rows: held across the whole epilogue they sat on top of the 128 live accumulator registers and pushed the
+        // kernel into scratch, which cost the two epilogue variants 11 us per launch)
         float s_l1 = 0.f, s_cnt = 0.f;                 // RELU partials
         float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);  // DPRE column sums (this lane's rows)
         const int64_t widx = (n0 + wn * 64) >> 6;        // this wave's word of a row's activity bits
@@ -215,6 +215,12 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
             __builtin_amdgcn_wave_barrier();
             unsigned long long keep = 0;  // RELU: lane (pr, j = i) keeps the activity word of row pr + 4 i; ONE store per 32 rows
             float keepmax = 0.f;
+            float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(1.f, 1.f, 1.f, 1.f), cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (EPI != GX_EPI_DPRE && e.bias && z == 0 && col_ok) bv4 = *(const float4*)(e.bias + ncol);
+            if (EPI != GX_EPI_PLAIN && e.colw && col_ok) w4 = *(const float4*)(e.colw + ncol);
+            if constexpr (FP8) {
+                if (col_ok) cs4 = *(const float4*)(e.cscale + ncol);  // fp8 operands: column (Bt row) dequantisation scales
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int rl = pr + 4 * i;

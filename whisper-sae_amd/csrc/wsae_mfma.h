@@ -231,6 +231,16 @@ __device__ __forceinline__ void glds16(const void* src, uint32_t lds_byte) {
                  : "v"(src), "s"(lds_addr)
                  : "memory");
 }
+// SGPR base + 32-bit per-lane byte offset form: one VGPR per piece instead of a 64-bit address pair (the persistent GEMMs hold
+// eight pieces' addresses across their whole tile loop: with pairs they ran out of registers)
+__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, uint32_t lds_byte) {
+    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(lds_byte);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
 // the same with the non-temporal policy: for operands every byte of which ONE workgroup reads once (a streamed [B, H] matrix)
 __device__ __forceinline__ void glds16_nt(const void* src, uint32_t lds_byte) {
     const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(lds_byte);
