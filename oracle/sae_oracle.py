@@ -432,12 +432,24 @@ def fp8_quant_rows(v: np.ndarray):
     return fp8_e4m3_round((v * inv[:, None]).astype(F32)), scale
 
 
+def fp8_quant_tensor(v: np.ndarray):
+    """Per-TENSOR e4m3 quantisation (one scale for the whole matrix, returned per row for the caller's convenience) as
+    wsae_relu.hip quantises the decoder weight: q = e4m3(v * (448 / amax)), scale = amax / 448, fp32 arithmetic.  The
+    decoder's columns are kept at unit norm, so its entries share one dynamic range; e4m3 is a floating-point format, the
+    relative precision of an entry does not depend on where in the range it sits."""
+    v = np.asarray(v, dtype=F32)
+    amax = F32(np.abs(v).max())
+    inv = F32(448.0) / amax if amax > 0 else F32(1)
+    scale = amax / F32(448.0) if amax > 0 else F32(1)
+    return fp8_e4m3_round((v * inv).astype(F32)), np.full(v.shape[0], scale, dtype=F32)
+
+
 def relu_forward(W_e, b_e, W_d, b_d, x, sparsity_weight: float = 0.01, mode: str = "fp32") -> dict:
     """model.py:304-322: hidden = relu(enc(x)); recon = dec(hidden); loss = mse + w * mean|hidden|.
 
     ``mode="fp8"`` mirrors the device's fp8 forward (BASELINE.json configs[4]; wsae_ctx_set_relu_fp8): both GEMMs on
-    e4m3 copies of their operands - x and bf16(hidden) per batch row, bf16(W_e) per feature row, bf16(W_d) per output
-    row - with fp32 accumulation and ``row scale * column scale`` applied to the accumulator before the bias."""
+    e4m3 copies of their operands - x and bf16(hidden) per batch row, bf16(W_e) per feature row, bf16(W_d) with ONE scale
+    for the matrix - with fp32 accumulation and ``row scale * column scale`` applied to the accumulator before the bias."""
     x = np.asarray(x, dtype=F32)
     if mode == "fp8":
         xq, sx = fp8_quant_rows(x)
@@ -445,7 +457,7 @@ def relu_forward(W_e, b_e, W_d, b_d, x, sparsity_weight: float = 0.01, mode: str
         pre = ((xq.astype(F64) @ wq.astype(F64).T).astype(F32) * (sx[:, None] * sw[None, :]).astype(F32) + b_e).astype(F32)
         hidden = np.maximum(pre, 0).astype(F32)
         hq, sh = fp8_quant_rows(bf16_round(hidden))
-        dq, sd = fp8_quant_rows(bf16_round(W_d))
+        dq, sd = fp8_quant_tensor(bf16_round(W_d))
         recon = ((hq.astype(F64) @ dq.astype(F64).T).astype(F32) * (sh[:, None] * sd[None, :]).astype(F32) + b_d).astype(F32)
     else:
         pre = (x.astype(F64) @ W_e.astype(F64).T + b_e.astype(F64)).astype(F32)

@@ -104,6 +104,8 @@ struct wsae_ctx {
     int ent_valid;        // 1: the last decode launch left the bucketed code of (ent_vals, ent_B) itself (chunked form)
     const float* ent_vals;
     int ent_B;
+    const float* wire_dec_vals;  // batch whose decoder half wsae_weight_grads_wire has just run (the encoder half must follow it)
+    int wire_dec_B;
     int32_t* counters;    // small int scratch (fallback rows, resample cursors; [16..) = arrival tickets, 8-byte aligned)
     int32_t* dead_list;   // [H] compacted dead feature indices (resample)
     int32_t* row_order;   // [maxB] rows sorted by error (resample)

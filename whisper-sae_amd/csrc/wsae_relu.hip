@@ -471,12 +471,12 @@ slab_sum8_kernel(const float* __restrict__ slabs, int64_t slab_stride, int nz, i
 }
 
 // squares of the two bias gradients (H + D values) as one more norm partial
-__global__ void __launch_bounds__(256) bias_sq_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb,
-                                                      float* __restrict__ out) {
-    __shared__ float red[8];
+__global__ void __launch_bounds__(1024) bias_sq_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb,
+                                                       float* __restrict__ out) {
+    __shared__ float red[16];
     float sq = 0.f;
-    for (int i = threadIdx.x; i < na; i += 256) sq = fmaf(a[i], a[i], sq);
-    for (int i = threadIdx.x; i < nb; i += 256) sq = fmaf(b[i], b[i], sq);
+    for (int i = threadIdx.x; i < na; i += 1024) sq = fmaf(a[i], a[i], sq);
+    for (int i = threadIdx.x; i < nb; i += 1024) sq = fmaf(b[i], b[i], sq);
     const float t = block_sum(sq, red);
     if (threadIdx.x == 0) *out = t;
 }
@@ -528,6 +528,78 @@ __global__ void __launch_bounds__(256) quant_rows_kernel(const void* __restrict_
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
         *(int2*)(q + (int64_t)r * C + c) = make_int2(lo, hi);
+    }
+}
+
+// ---- per-TENSOR e4m3 quantisation of the decoder weight (its columns are kept at unit norm: one dynamic range) -------------
+// amax partials (one per block, no atomics; the consumers below reduce them again - at most 1024 values - in their prologue)
+__global__ void __launch_bounds__(256) tensor_amax_kernel(const bf16_t* __restrict__ src, int64_t n8, float* __restrict__ pmax) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 v = ((const bf16x8*)src)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) pmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__device__ __forceinline__ float amax_of_partials(const float* __restrict__ pmax, int nparts, float* red) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, pmax[i]);
+    m = wave_max(m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// W_dT bf16 [H][D] -> e4m3 W_d [D][H] (K = h contiguous: the NT operand of the decoder GEMM) with the tensor's scale, one pass
+__global__ void __launch_bounds__(256)
+transpose_quant_kernel(const bf16_t* __restrict__ src, const float* __restrict__ pmax, int nparts, uint8_t* __restrict__ q,
+                       float* __restrict__ scale, int H, int D) {
+    __shared__ float tile[64][65];
+    __shared__ float red[4];
+    const float amax = amax_of_partials(pmax, nparts, red);
+    const float inv = amax > 0.f ? 448.f / amax : 1.f;
+    const int h0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    if (blockIdx.x == 0 && threadIdx.x < 64 && d0 + (int)threadIdx.x < D) scale[d0 + threadIdx.x] = amax > 0.f ? amax / 448.f : 1.f;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int hl = i >> 6, dl = i & 63;
+        tile[hl][dl] = (h0 + hl < H && d0 + dl < D) ? (float)src[(int64_t)(h0 + hl) * D + d0 + dl] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256) {  // 64 output rows (d) x 16 groups of 4 consecutive h
+        const int dl = i >> 4, g4 = (i & 15) * 4;
+        if (d0 + dl >= D || h0 + g4 >= H) continue;  // (H is a multiple of 4)
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(tile[g4][dl] * inv, tile[g4 + 1][dl] * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(tile[g4 + 2][dl] * inv, tile[g4 + 3][dl] * inv, w, true);
+        *(int*)(q + (int64_t)(d0 + dl) * H + h0 + g4) = w;
+    }
+}
+
+// the general path's W_d [D][H] bf16 (already transposed) with the tensor's scale, one pass
+__global__ void __launch_bounds__(256)
+quant_fixed_kernel(const bf16_t* __restrict__ src, const float* __restrict__ pmax, int nparts, int R, int C, uint8_t* __restrict__ q,
+                   float* __restrict__ scale) {
+    __shared__ float red[4];
+    const float amax = amax_of_partials(pmax, nparts, red);
+    const float inv = amax > 0.f ? 448.f / amax : 1.f;
+    const int64_t n8 = (int64_t)R * C / 8;
+    if (blockIdx.x == 0)
+        for (int r = threadIdx.x; r < R; r += 256) scale[r] = amax > 0.f ? amax / 448.f : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 a = ((const bf16x8*)src)[i];
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)a[0] * inv, (float)a[1] * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)a[2] * inv, (float)a[3] * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)a[4] * inv, (float)a[5] * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)a[6] * inv, (float)a[7] * inv, hi, true);
+        ((int2*)q)[i] = make_int2(lo, hi);
     }
 }
 
@@ -615,8 +687,11 @@ int forward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     e2.c = ctx->pre; e2.ldc = D; e2.cz = (int64_t)B * D;  // two split-K slabs in the (otherwise unused) pre-activation scratch
     if (fp8) {
         quant_hidden_kernel<<<B, 256, 0, st>>>((const bf16_t*)ws.hid, rowmax, ldT, B, H, ws.hidq, ws.sh);
-        transpose_w_kernel<bf16_t><<<dim3(ceil_div(H, 64), ceil_div(D, 64)), 256, 0, st>>>(ctx->WdT_bf16, (bf16_t*)ws.wd_nt, H, D);
-        quant_rows(st, ws.wd_nt, WSAE_DT_BF16, nullptr, D, H, ws.wdq, ws.swd);
+        // the decoder weight with ONE scale (unit-norm columns: one dynamic range): amax partials, then transposition and
+        // quantisation in a single pass (round-3 first cut: transpose + two-pass per-row quantisation, 184 us at 1280 -> 40960)
+        const int npm = 1024;
+        tensor_amax_kernel<<<npm, 256, 0, st>>>(ctx->WdT_bf16, (int64_t)H * D / 8, ctx->part_sq);  // (the norm-partial slots are free here)
+        transpose_quant_kernel<<<dim3(ceil_div(H, 64), ceil_div(D, 64)), 256, 0, st>>>(ctx->WdT_bf16, ctx->part_sq, npm, ws.wdq, ws.swd, H, D);
         e2.rscale = ws.sh; e2.cscale = ws.swd;
         WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 0, GX_EPI_PLAIN, ws.hidq, H, ws.wdq, H, B, D, H, 2, e2, st, 1),
                      "wsae_relu_forward: fp8 decoder GEMM rejected B %d, D %d, H %d", B, D, H);
@@ -682,7 +757,7 @@ int backward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
     const int nb1 = ceil_div(H, 64);
     colsum2_kernel<<<nb1 + ceil_div(D, 64), 256, 0, st>>>(ws.colpart, B / 128, H, grads + ctx->off[2], nb1, ctx->part_dbd,
                                                           ceil_div(B, 64), D, grads + ctx->off[3], grads + ctx->off[4]);
-    bias_sq_kernel<<<1, 256, 0, st>>>(grads + ctx->off[2], H, grads + ctx->off[3], D, ctx->part_sq + nsq);
+    bias_sq_kernel<<<1, 1024, 0, st>>>(grads + ctx->off[2], H, grads + ctx->off[3], D, ctx->part_sq + nsq);
     WSAE_LAUNCH_CHECK();
     ctx->n_sq_parts = nsq + 1;  // wsae_adamw_step(norm_from_wgrad = 1) sums these: no separate norm pass
     ctx->g_is_bf16 = 1;
@@ -716,7 +791,8 @@ int forward_t(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
     relu_act_kernel<T><<<ga, 256, 0, st>>>(ctx->pre, hidden, (T*)ws.hid, (T*)ws.hidT, B, H, ldT, ws.part, ws.nblk, ctx->relu_l1w);
     if (fp8) {
         quant_rows(st, ws.hid, WSAE_DT_BF16, nullptr, B, H, ws.hidq, ws.sh);
-        quant_rows(st, ws.wd_nt, WSAE_DT_BF16, nullptr, D, H, ws.wdq, ws.swd);
+        tensor_amax_kernel<<<1024, 256, 0, st>>>((const bf16_t*)ws.wd_nt, (int64_t)H * D / 8, ctx->part_sq);
+        quant_fixed_kernel<<<1024, 256, 0, st>>>((const bf16_t*)ws.wd_nt, ctx->part_sq, 1024, D, H, ws.wdq, ws.swd);
         WSAE_REQUIRE(wsae_internal_gemm256d_fp8(ctx, ws.hidq, H, ws.wdq, H, ws.sh, ws.swd, params + ctx->off[3], recon, D, B, D, H, st),
                      "wsae_relu_forward: the fp8 forward needs input_dim >= 128 and hidden_dim %% 256 == 0 (got D %d, H %d)", D, H);
     } else {

@@ -1137,6 +1137,10 @@ static int weight_grads_impl(wsae_ctx* ctx, const float* params, const void* x, 
                  "wsae_wgrad_parts_supported)");
     // the code is sorted once per batch: by the first launch that needs it (the decoder half, or the single launch)
     const bool sort_code = part != WSAE_PART_ENCODER;
+    WSAE_REQUIRE(part != WSAE_PART_ENCODER || (ctx->wire_dec_vals == vals && ctx->wire_dec_B == B),
+                 "wsae_weight_grads_wire: WSAE_PART_ENCODER must follow WSAE_PART_DECODER of the same batch (it reads the code that call sorted)");
+    ctx->wire_dec_vals = part == WSAE_PART_DECODER ? vals : nullptr;
+    ctx->wire_dec_B = part == WSAE_PART_DECODER ? B : 0;
     float* out = ctx->wg_slabs;
     if (bf) launch_wgrad<bf16_t>(ctx, p, st, vals, idx, dpre, B, out, x, rows, sort_code);
     else launch_wgrad<float>(ctx, p, st, vals, idx, dpre, B, out, x, rows, sort_code);
