@@ -327,6 +327,15 @@ def main() -> None:
         }
         if args.profile_all:
             out["kernel_ms_per_step"] = {k: v[1] / max(v[0], 1) for k, v in prof.items()}
+        if not args.relu:
+            # selective strip stores of the encoder GEMM (include/wsae.h): rows that had to recompute strips over the whole
+            # run (warm-up, timed windows, probe) and the last batch's smallest row threshold
+            import ctypes
+            rows_c, tmin_c, s_c = ctypes.c_int64(0), ctypes.c_float(0.0), ctypes.c_float(0.0)
+            N.check(N.lib().wsae_ctx_strip_stats(handle, ctypes.addressof(rows_c), ctypes.addressof(tmin_c), ctypes.addressof(s_c)),
+                    "wsae_ctx_strip_stats")
+            out["strip_predict"] = {"enabled": os.environ.get("WSAE_STRIP_PREDICT", "1") != "0", "refilled_rows": rows_c.value,
+                                    "last_min_threshold": tmin_c.value, "margin": s_c.value}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B)
         print(json.dumps(out))

@@ -103,6 +103,23 @@ int wsae_ctx_destroy(wsae_ctx* ctx);
  * every rank).  Replaces the 8*H-byte MAX all-reduce the reference's semantics would otherwise need
  * under DDP (the reference itself is single-process). */
 int wsae_ctx_set_fired(wsae_ctx* ctx, float* fired);
+/* Selective strip stores of the encoder GEMM (no counterpart in the reference: a property of this implementation of
+ * model.py:111-114).  The TopK of wsae_encode_topk / wsae_encode_decode reads a 16-column strip of the pre-activation
+ * matrix only when the strip's maximum reaches the row's threshold T, so for batches served by the persistent GEMM
+ * (bf16 mode, B >= 2048) that GEMM writes to HBM only the strips whose maximum reaches s x the smallest T of the
+ * previous TWO batches on this ctx, with a margin s that adapts by itself (0.25 .. 1; wsae_topk.h).  The prediction is
+ * verified row by row in the TopK launch, and a row that needs a strip that was not stored recomputes it with the GEMM's
+ * own arithmetic: outputs are bit-identical with the feature on or off, whatever the history; only the time differs
+ * (DESIGN.md section 4.1).
+ *   on: 0 disables, non-zero enables (default: enabled, or disabled when the environment has WSAE_STRIP_PREDICT=0 at
+ *   wsae_ctx_create time - for A/B timing runs; WSAE_STRIP_SAFETY=<s> there fixes the margin).
+ *   assume_store_threshold: NaN forgets the history (the next launch stores every strip); any other value is the store
+ *   threshold the next launch uses (tests pass a huge value to force every row through the recompute path). */
+int wsae_ctx_set_strip_predict(wsae_ctx* ctx, int32_t on, float assume_store_threshold);
+/* refilled_rows: rows that recomputed strips since the ctx was created (cumulative); last_min_threshold: the smallest row
+ * threshold of the last predicated TopK launch (NaN when there is none); margin: the s of the last predicated GEMM launch
+ * (0 when there is none).  Synchronises the device. */
+int wsae_ctx_strip_stats(wsae_ctx* ctx, int64_t* refilled_rows, float* last_min_threshold, float* margin);
 /* Number of columns the reconstruction MSE (and g = 2 r / (B cols)) averages over; default input_dim.  A transcoder
  * whose output is narrower than its input runs on a ctx padded to the wider of the two and sets this to its
  * output_dim (F.mse_loss means over B * output_dim, transcoder.py:152). */

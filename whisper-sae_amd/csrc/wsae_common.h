@@ -89,6 +89,14 @@ struct wsae_ctx {
     float* pre;           // [maxB][H] pre-activation scratch (TopK input)
     float* smax;          // [maxB][H/16] maxima of the 16-column strips of pre (written by the persistent GEMM)
     int smax_valid;       // 1 when smax matches the pre the last dense GEMM wrote
+    // selective strip stores (wsae_topk.h, "strip store threshold")
+    uint32_t* tmin;       // three groups of minimum slots (wsae_topk.h, TG_GROUP_WORDS each) in rotation, then the count of rows that recomputed strips
+    int tmin_cur;         // slot the current batch's TopK launch fills (the GEMM read the other two)
+    int strip_predict;    // 1 (default): the encoder GEMM of encode_topk stores strips selectively
+    float tg_fixed_s;     // > 0: fixed margin s of the store threshold instead of the adaptive one (WSAE_STRIP_SAFETY, experiments)
+    int pred_valid;       // 1: pre holds only the strips above the threshold; the TopK launch must check rows against it
+    const void* pred_x;   // that GEMM's A operand and row list (what a row recomputes its missing strips from)
+    const int32_t* pred_rows;
     float* part_loss;     // [WSAE_MAX_PARTIALS]
     float* part_l0;       // [WSAE_MAX_PARTIALS]
     float* part_dbd;      // [WSAE_MAX_PARTIALS][D]
@@ -250,7 +258,7 @@ __device__ __forceinline__ float load_act(const void* p, int64_t i) {
 int wsae_internal_stage(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, hipStream_t st);
 int wsae_internal_stage_rows(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B, hipStream_t st);
 int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,
-                                 int B, float* pre, int64_t* step_count, int direct, hipStream_t st);
+                                 int B, float* pre, int64_t* step_count, int direct, hipStream_t st, bool predicate = false);
 // internal (wsae_encode.hip): the standalone TopK launch over ctx->pre; whether the strip-guided form applies
 int wsae_internal_topk(wsae_ctx* ctx, int B, float* vals, int32_t* idx, int32_t* fb, hipStream_t st);
 int wsae_internal_encode_topk(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,

@@ -6,6 +6,9 @@
 #include <new>
 
 #include "wsae_common.h"
+#include "wsae_topk.h"
+#include <cstdlib>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 static void prof_free(wsae_ctx* c);
@@ -116,6 +119,7 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     const size_t o_eo = cv.take((size_t)((maxB + 31) / 32) * ((H + 127) / 128 + 1) * 4);
     const size_t o_dl = cv.take((size_t)H * 4);
     const size_t o_ro = cv.take((size_t)maxB * 4);
+    const size_t o_tm = cv.take(TG_WORDS * 4);
     char* base = nullptr;
     hipError_t e = hipMalloc((void**)&base, cv.total);
     if (e != hipSuccess) {
@@ -156,6 +160,11 @@ extern "C" int wsae_ctx_create(const wsae_config* cfg, wsae_ctx** out) {
     c->ent_off = (int32_t*)(base + o_eo);
     c->dead_list = (int32_t*)(base + o_dl);
     c->row_order = (int32_t*)(base + o_ro);
+    c->tmin = (uint32_t*)(base + o_tm);
+    const char* sp = getenv("WSAE_STRIP_PREDICT");  // (A/B runs: "0" creates contexts with the selective strip stores off)
+    c->strip_predict = (sp && sp[0] == '0') ? 0 : 1;
+    const char* ss = getenv("WSAE_STRIP_SAFETY");
+    c->tg_fixed_s = ss ? (float)atof(ss) : 0.f;
     c->ws_bytes = cv.total;
     *out = c;
     return WSAE_OK;
@@ -235,6 +244,51 @@ extern "C" int wsae_profile_read(wsae_ctx* ctx, int32_t kernel_id, int32_t* n_la
 extern "C" int wsae_ctx_set_fired(wsae_ctx* ctx, float* fired) {
     WSAE_REQUIRE(ctx, "wsae_ctx_set_fired: null ctx");
     ctx->fired = fired;
+    return WSAE_OK;
+}
+
+// Selective strip stores of the encoder GEMM (wsae_topk.h, "strip store threshold"; include/wsae.h).
+static uint32_t host_f32_ord(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+extern "C" int wsae_ctx_set_strip_predict(wsae_ctx* ctx, int32_t on, float assume_store_threshold) {
+    WSAE_REQUIRE(ctx, "wsae_ctx_set_strip_predict: null ctx");
+    ctx->strip_predict = on ? 1 : 0;
+    ctx->pred_valid = 0;
+    // the next encoder launch moves on to group tmin_cur + 1 and reads the other two.
+    // NaN: forget the history (the next launch stores every strip, the margin starts over); otherwise make the next launch
+    // store with exactly this threshold (a predecessor whose minimum was this value, margin 1, no misses; none before it)
+    WSAE_HIP_CHECK(hipDeviceSynchronize());
+    const bool forget = assume_store_threshold != assume_store_threshold;
+    const float one = 1.0f;
+    uint32_t hdr[3] = {forget ? 0u : host_f32_ord(assume_store_threshold), 0u, 0u};  // minimum slot 0, margin, misses
+    if (!forget) memcpy(&hdr[1], &one, 4);
+    uint32_t* prev = ctx->tmin + ctx->tmin_cur * TG_GROUP_WORDS;  // the group the next launch sees as its predecessor
+    WSAE_HIP_CHECK(hipMemset(prev, 0, TG_GROUP_WORDS * 4));
+    WSAE_HIP_CHECK(hipMemset(ctx->tmin + ((ctx->tmin_cur + 2) % 3) * TG_GROUP_WORDS, 0, TG_GROUP_WORDS * 4));
+    WSAE_HIP_CHECK(hipMemcpy(prev, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+    return WSAE_OK;
+}
+extern "C" int wsae_ctx_strip_stats(wsae_ctx* ctx, int64_t* refilled_rows, float* last_min_threshold, float* margin) {
+    WSAE_REQUIRE(ctx && refilled_rows && last_min_threshold && margin, "wsae_ctx_strip_stats: null argument");
+    std::vector<uint32_t> h(TG_WORDS);
+    WSAE_HIP_CHECK(hipDeviceSynchronize());
+    WSAE_HIP_CHECK(hipMemcpy(h.data(), ctx->tmin, h.size() * 4, hipMemcpyDeviceToHost));
+    *refilled_rows = (int64_t)h[TG_REFILLED];
+    uint32_t o = 0xFFFFFFFFu;
+    for (int i = 0; i < TG_SLOTS; ++i) {
+        const uint32_t s = h[ctx->tmin_cur * TG_GROUP_WORDS + i * TG_SLOT_STRIDE];
+        if (s != 0u && s < o) o = s;
+    }
+    float f = NAN;
+    if (o != 0u && o != 0xFFFFFFFFu) {
+        const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+        memcpy(&f, &u, 4);
+    }
+    *last_min_threshold = f;
+    memcpy(margin, &h[ctx->tmin_cur * TG_GROUP_WORDS + TG_HDR_S], 4);
     return WSAE_OK;
 }
 

@@ -120,7 +120,8 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
                        const float* __restrict__ bias, float* __restrict__ pre, int64_t ldp, int B, int H, int D, int ntn,
                        int ntiles_mn, int nsplit, int64_t cz, float* __restrict__ smax, const int32_t* __restrict__ arows,
                        int64_t* __restrict__ step_count, const float* __restrict__ rscale = nullptr,
-                       const float* __restrict__ cscale = nullptr) {
+                       const float* __restrict__ cscale = nullptr, uint32_t* __restrict__ tmin = nullptr, int tmin_cur = 0,
+                       float tg_fixed_s = 0.f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = SWZ_ROW_BYTES / (int)sizeof(T);
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -136,6 +137,24 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
     // (the encoder forward gathers its batch rows straight from the activation ring: A row m is xb[arows[m]]; it is
     // then also the first kernel of the step and advances the dead-feature clock of model.py:175)
     if (step_count && blockIdx.x == 0 && tid == 0) *step_count += 1;
+    // strip store threshold (wsae_topk.h): from the smallest row thresholds the last two TopK launches saw; this launch
+    // re-arms the slot its own TopK launch will fill (which nobody reads meanwhile)
+    // (wave 0 works it out - its loads overlap the first slab's DMA - and the others pick it up after the K loop's barriers)
+    __shared__ float tg_sh;
+    if (wave == 0) {
+        float s_now = 0.f;
+        const float t = tmin ? strip_store_threshold(tmin, tmin_cur, lane, tg_fixed_s, &s_now) : -INFINITY;
+        if (lane == 0) tg_sh = t;
+        if (tmin && blockIdx.x == 0) {
+            uint32_t* grp = tmin + tmin_cur * TG_GROUP_WORDS;
+            grp[lane * TG_SLOT_STRIDE] = 0xFFFFFFFFu;
+            if (lane == 0) {
+                grp[TG_HDR_S] = __float_as_uint(s_now);
+                grp[TG_HDR_MISSES] = 0u;
+                __builtin_nontemporal_store(t, (float*)tmin + TG_USED);  // what the TopK launch checks rows against
+            }
+        }
+    }
 
     const int ntiles = ntiles_mn * nsplit;  // work items: (K range z, tile)
     const int ntm = ntiles_mn / ntn;
@@ -220,6 +239,7 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
         // buffer stores addressed by one per-lane byte offset + a scalar row offset, strip maxima on v_max3 /
         // v_max_f32_dpp (fmaxf would canonicalise every operand first): ~130 vector instructions per row group
         // against ~250 vector + ~150 scalar ones in the general form below.
+        const float tg = tg_sh;
         const bool fast = !rscale && smax && z == 0 && m0 + 256 <= B && n0 + 256 <= H && (int64_t)B * ldp < (1ll << 29);
         if (fast) {
             typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -246,8 +266,6 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
                     va.x += bv4.x; va.y += bv4.y; va.z += bv4.z; va.w += bv4.w;
                     vb.x += bv4.x; vb.y += bv4.y; vb.z += bv4.z; vb.w += bv4.w;
                     const int q = mi * 8 + i;  // 4-row group inside the wave's 128 rows
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, va), r_pre, off_pre, q * row_pre, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, vb), r_pre, off_pre, (q + 1) * row_pre, 0);
                     float ma, mb, ta, tb;  // (two rows per block: the second chain fills the first one's DPP wait states)
                     asm volatile(
                         "v_max3_f32 %0, %4, %5, %6\n\t"
@@ -266,6 +284,10 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
                     // memory pipe the same with 16 lanes as with 64, and no exec switching is needed)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ma), r_sm, off_sm, q * row_sm, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mb), r_sm, off_sm, (q + 1) * row_sm, 0);
+                    // the strip itself only when its maximum reaches the store threshold (wsae_topk.h, "strip store
+                    // threshold"): the TopK reads nothing below it, and recomputes the strip in the rare row where it must
+                    if (!(ma < tg)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, va), r_pre, off_pre, q * row_pre, 0);
+                    if (!(mb < tg)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, vb), r_pre, off_pre, (q + 1) * row_pre, 0);
                 }
                 __builtin_amdgcn_wave_barrier();
                 EN_T(7)
@@ -542,16 +564,20 @@ topk_rows_kernel(const float* __restrict__ pre, int B, int H, int K, float* __re
 }
 
 template <int SPL, int NTOP>
-__global__ void __launch_bounds__(256)
-topk_strips_kernel(const float* __restrict__ pre, const float* __restrict__ smax, int B, int H, int K,
-                   float* __restrict__ vals, int32_t* __restrict__ idx, int32_t* __restrict__ fallback_rows) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))  // (the refill path may spill; the common path fits)
+topk_strips_kernel(const float* pre, const float* __restrict__ smax, int B, int H, int K,
+                   float* __restrict__ vals, int32_t* __restrict__ idx, int32_t* __restrict__ fallback_rows, StripFix fix,
+                   const uint32_t* tmin) {
     __shared__ uint64_t lists[4][TOPK_CAP];
     __shared__ int strips[4][TS_MAX_STRIPS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
     if (b >= B) return;
+    // (tmin: the encoder GEMM of this batch stored strips selectively and left its threshold there; null: it stored every strip)
+    fix.tg = tmin ? *(const float*)(tmin + TG_USED) : -INFINITY;
     topk_strips_row<SPL, NTOP, TOPK_CAP>(pre + (int64_t)b * H, smax + (int64_t)b * (H >> 4), H, K, lane, lists[wave],
-                                         strips[wave], vals + (int64_t)b * K, idx + (int64_t)b * K, fallback_rows);
+                                         strips[wave], vals + (int64_t)b * K, idx + (int64_t)b * K, fallback_rows, nullptr,
+                                         nullptr, tmin != nullptr, fix, b);
 }
 
 // hidden = zeros; hidden[b][idx] = relu(val)        (model.py:115-116)
@@ -602,7 +628,7 @@ static bool persistent_ok(const wsae_ctx* c, int B) {
 // row indices (the ring gather done by the GEMM itself; then step_count, if given, is advanced by this launch)
 template <typename T>
 static int gemm_dense(wsae_ctx* c, const float* params, int B, float* pre, int ldp, const T* xa, const int32_t* arows,
-                      int64_t* step_count, hipStream_t st) {
+                      int64_t* step_count, hipStream_t st, bool predicate = false) {
     const T* W = sizeof(T) == 2 ? (const T*)c->We_bf16 : (const T*)(params + c->off[0]);
     const float* bias = sizeof(T) == 2 ? c->c_fold : params + c->off[2];
     const int H = c->H;
@@ -610,15 +636,26 @@ static int gemm_dense(wsae_ctx* c, const float* params, int B, float* pre, int l
     if (persistent_ok<T>(c, B)) {
         const int ntn = H / 256, ntiles = ntn * ceil_div(B, 256);
         float* smax = (pre == c->pre && ldp == H) ? c->smax : nullptr;
+        // selective strip stores (wsae_topk.h): only for the strip-guided TopK launch that follows in encode_topk
+        uint32_t* tmin = nullptr;
+        if (pre == c->pre) c->pred_valid = 0;
+        if (predicate && smax && sizeof(T) == 2) {
+            c->tmin_cur = (c->tmin_cur + 1) % 3;
+            tmin = c->tmin;
+            c->pred_valid = 1;
+            c->pred_x = xa;
+            c->pred_rows = arows;
+        }
         encode_gemm256d_kernel<T><<<min(ntiles, c->cus), 512, G256D_LDS, st>>>(xa, c->D, W, c->D, bias, pre, ldp, B, H, c->D, ntn,
-                                                                              ntiles, 1, 0, smax, arows, step_count);
+                                                                              ntiles, 1, 0, smax, arows, step_count, nullptr,
+                                                                              nullptr, tmin, c->tmin_cur, c->tg_fixed_s);
         if (pre == c->pre) c->smax_valid = smax ? 1 : 0;
     } else if (sizeof(T) == 2 && B <= 1024 && c->D % 16 == 0) {
-        if (pre == c->pre) c->smax_valid = 0;
+        if (pre == c->pre) c->smax_valid = c->pred_valid = 0;
         encode_direct_kernel<<<dim3(ceil_div(H, 32), ceil_div(B, 128)), 256, 0, st>>>((const bf16_t*)xa, arows, (const bf16_t*)W, bias, pre,
                                                                                      ldp, B, H, c->D, step_count);
     } else {
-        if (pre == c->pre) c->smax_valid = 0;
+        if (pre == c->pre) c->smax_valid = c->pred_valid = 0;
         dim3 gg(ceil_div(H, TILE_N), ceil_div(B, TILE_M));
         encode_gemm_kernel<T><<<gg, 256, 2 * TILE_LDS_BYTES, st>>>(xa, W, bias, pre, ldp, B, H, c->D, arows, step_count);
     }
@@ -632,17 +669,17 @@ static int gemm_dense(wsae_ctx* c, const float* params, int B, float* pre, int l
 // launch (ctx->xT_valid = 0 tells it so).  Everything else stages xb / xT first.
 template <typename T>
 static int stage_and_gemm(wsae_ctx* c, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,
-                          float* pre, int64_t* step_count, int direct, hipStream_t st) {
+                          float* pre, int64_t* step_count, int direct, hipStream_t st, bool predicate = false) {
     // (the persistent kernel for large batches; below its minimum the 128 x 128 kernel takes the row list the same way: at the
     // reference's own batch sizes the staging launch was 5 of the step's ~80 us of kernels)
     if (direct && sizeof(T) == 2 && x_dtype == WSAE_DT_BF16) {
         c->xT_valid = 0;
-        return gemm_dense<T>(c, params, B, pre, c->H, (const T*)x, rows, step_count, st);
+        return gemm_dense<T>(c, params, B, pre, c->H, (const T*)x, rows, step_count, st, predicate);
     }
     int rc = stage_batch<T>(c, params, x, x_dtype, rows, B, step_count, st);
     if (rc) return rc;
     c->xT_valid = 1;
-    return gemm_dense<T>(c, params, B, pre, c->H, (const T*)c->xb, nullptr, nullptr, st);
+    return gemm_dense<T>(c, params, B, pre, c->H, (const T*)c->xb, nullptr, nullptr, st, predicate);
 }
 
 static int check_batch(const wsae_ctx* c, const void* x, int x_dtype, int B, const char* who) {
@@ -703,9 +740,9 @@ int wsae_internal_stage_rows(wsae_ctx* ctx, const float* params, const void* x, 
 }
 
 int wsae_internal_stage_and_gemm(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows,
-                                 int B, float* pre, int64_t* step_count, int direct, hipStream_t st) {
-    return ctx->prec == WSAE_PREC_BF16 ? stage_and_gemm<bf16_t>(ctx, params, x, x_dtype, rows, B, pre, step_count, direct, st)
-                                       : stage_and_gemm<float>(ctx, params, x, x_dtype, rows, B, pre, step_count, direct, st);
+                                 int B, float* pre, int64_t* step_count, int direct, hipStream_t st, bool predicate) {
+    return ctx->prec == WSAE_PREC_BF16 ? stage_and_gemm<bf16_t>(ctx, params, x, x_dtype, rows, B, pre, step_count, direct, st, predicate)
+                                       : stage_and_gemm<float>(ctx, params, x, x_dtype, rows, B, pre, step_count, direct, st, false);
 }
 
 extern "C" int wsae_encode_dense(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype,
@@ -728,7 +765,22 @@ int wsae_internal_topk(wsae_ctx* ctx, int B, float* vals, int32_t* idx, int32_t*
     const int ns = ctx->H / 16;
     const dim3 tg(ceil_div(B, 4));
     if (wsae_internal_strips_ok(ctx)) {
-#define TS_ARGS ctx->pre, ctx->smax, B, ctx->H, ctx->K, vals, idx, fb
+        // the GEMM stored this batch's strips selectively: this launch checks every row against the same threshold,
+        // fills in what a row is missing and leaves its own minimum for the next GEMM (wsae_topk.h)
+        StripFix fix = {};
+        const uint32_t* tmin = nullptr;
+        if (ctx->pred_valid) {
+            fix.x = (const bf16_t*)ctx->pred_x;
+            fix.arows = ctx->pred_rows;
+            fix.We = ctx->We_bf16;
+            fix.bias = ctx->c_fold;
+            fix.D = ctx->D;
+            fix.tmin_group = ctx->tmin + ctx->tmin_cur * TG_GROUP_WORDS;
+            fix.miss_rows = (int32_t*)(ctx->tmin + TG_REFILLED);
+            tmin = ctx->tmin;
+            ctx->pred_valid = 0;  // (pre is consumed: a second TopK over it would find the slots moved on)
+        }
+#define TS_ARGS ctx->pre, ctx->smax, B, ctx->H, ctx->K, vals, idx, fb, fix, tmin
         if (ctx->K <= 32) {
             if (ns <= 192) topk_strips_kernel<3, 1><<<tg, 256, 0, st>>>(TS_ARGS);
             else if (ns <= 512) topk_strips_kernel<8, 1><<<tg, 256, 0, st>>>(TS_ARGS);
@@ -755,8 +807,13 @@ int wsae_internal_topk(wsae_ctx* ctx, int B, float* vals, int32_t* idx, int32_t*
 // encoder + TopK of one batch: the dense GEMM into ctx->pre followed by a TopK launch
 int wsae_internal_encode_topk(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, const int32_t* rows, int B,
                               float* vals, int32_t* idx, int64_t* step_count, int32_t* fb, hipStream_t st) {
-    int rc = wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, step_count, 1, st);
+    // (selective strip stores need the strip-guided TopK right behind the GEMM: the conditions of wsae_internal_strips_ok
+    // that do not depend on the launch)
+    const int ns = ctx->H / 16;
+    const bool predicate = ctx->strip_predict && ctx->K <= 64 && ctx->H % 16 == 0 && ns >= 128 && ns <= 1024;
+    int rc = wsae_internal_stage_and_gemm(ctx, params, x, x_dtype, rows, B, ctx->pre, step_count, 1, st, predicate);
     if (rc) return rc;
+    WSAE_REQUIRE(!ctx->pred_valid || wsae_internal_strips_ok(ctx), "encode_topk: selective strip stores without the strip-guided TopK");
     return wsae_internal_topk(ctx, B, vals, idx, fb, st);
 }
 

@@ -192,11 +192,242 @@ __device__ __noinline__ void topk_row_generic(const float* row, int H, int K, ui
 // ------------------------------------------------------------------------------------------------
 #define TS_MAX_STRIPS 128
 
+// ------------------------------------------------------------------------------------------------
+// Strip store threshold.  The selection above reads a strip only when its maximum is >= the row's T, so the encoder
+// GEMM need not write the strips below T to HBM at all - but it finishes a row's strips long before the row's T
+// exists.  It therefore predicts: every TopK launch leaves the smallest T of (a sample of) its batch behind, and the
+// NEXT encoder launch stores only the strips whose maximum reaches
+//     tg = s * (the smaller of the last TWO launches' minima - callers that alternate between two kinds of batches,
+//          training and validation say, are then predicted from the right kind as well)
+// (everything when there is no history or that minimum is <= 0).
+// The prediction is checked, not trusted: a row whose own T turns out below tg first tries the selection at tg itself
+// (every element >= tg is in a stored strip: with K of them nothing is missing after all) and otherwise - or when it
+// needs the exact full-row path - recomputes the strips it is missing right here: the same MFMA, the same K order,
+// the same bias add as the encoder GEMM's (encode_gemm256d_kernel / Mfma256s<bf16_t>), so the values are the ones
+// the GEMM would have stored, bit for bit, written into the row before it is read.  Results never depend on the
+// prediction; only the time does (measured: DESIGN.md section 4.1).
+// A row that recomputes strips holds its TopK launch up by tens of microseconds, so the margin s looks after itself:
+// it starts at TG_S_START, loses a tenth whenever the previous launch had such a row and otherwise creeps up by
+// TG_S_UP per launch to at most TG_S_MAX - on data whose row thresholds scatter widely it settles low (at TG_S_MIN
+// hardly a strip is skipped and hardly a row can miss), on well-behaved data just below the batch minimum.
+// ------------------------------------------------------------------------------------------------
+#define TG_S_START 0.9f
+#define TG_S_MAX 1.0f
+#define TG_S_MIN 0.25f
+#define TG_S_DOWN 0.9f
+#define TG_S_UP 0.002f
+
+// slots: three groups used in rotation; `cur` is the group of the current batch (its GEMM launch re-arms it, its TopK
+// launch fills it), the other two belong to the two batches before it.  A group: TG_SLOTS minimum words, TG_SLOT_STRIDE
+// apart (one L2 channel each, so that the atomic minima of a launch do not queue on one address; 0 / 0xFFFFFFFF: never
+// filled), and in the gap after the first slot the margin s its GEMM launch used and the number of rows that recomputed
+// strips in its TopK launch.  strip_store_threshold is called by whole waves - of the GEMM only (128 cache lines per
+// call): block 0 leaves the threshold in the word TG_USED for the TopK launch to read.
+#define TG_SLOTS 64
+#define TG_SLOT_STRIDE 64   // words
+#define TG_GROUP_WORDS (TG_SLOTS * TG_SLOT_STRIDE)
+#define TG_HDR_S 1          // float, word offset inside the group
+#define TG_HDR_MISSES 2     // int
+#define TG_USED (3 * TG_GROUP_WORDS)        // float: the store threshold of the last predicated GEMM launch
+#define TG_REFILLED (3 * TG_GROUP_WORDS + 1)  // int: rows that recomputed strips, cumulative
+#define TG_WORDS (3 * TG_GROUP_WORDS + 16)
+
+// fixed_s > 0: use this margin instead of the adaptive one (experiments).  *s_out: the margin of this launch.
+__device__ __forceinline__ float strip_store_threshold(const uint32_t* slots, int cur, int lane, float fixed_s, float* s_out) {
+    const uint32_t* prev = slots + ((cur + 2) % 3) * TG_GROUP_WORDS;
+    const uint32_t* prev2 = slots + ((cur + 1) % 3) * TG_GROUP_WORDS;
+    uint32_t a = __builtin_nontemporal_load(prev + lane * TG_SLOT_STRIDE);
+    uint32_t b = __builtin_nontemporal_load(prev2 + lane * TG_SLOT_STRIDE);
+    const float s_prev = __uint_as_float(__builtin_nontemporal_load(prev + TG_HDR_S));
+    const int misses = (int)__builtin_nontemporal_load(prev + TG_HDR_MISSES);
+    float s = !(s_prev > 0.f) ? TG_S_START : misses > 0 ? fmaxf(s_prev * TG_S_DOWN, TG_S_MIN) : fminf(s_prev + TG_S_UP, TG_S_MAX);
+    if (fixed_s > 0.f) s = fixed_s;
+    *s_out = s;
+    if (a == 0u) a = 0xFFFFFFFFu;
+    if (b == 0u) b = 0xFFFFFFFFu;
+    uint32_t o = a < b ? a : b;
+    o = min(o, lane_xor_u32<1>(o, lane));
+    o = min(o, lane_xor_u32<2>(o, lane));
+    o = min(o, lane_xor_u32<4>(o, lane));
+    o = min(o, lane_xor_u32<8>(o, lane));
+    o = min(o, lane_xor_u32<16>(o, lane));
+    o = min(o, lane_xor_u32<32>(o, lane));
+    o = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
+    if (o == 0xFFFFFFFFu) return -INFINITY;  // no history: store everything
+    const float t = ord_f32(o);
+    return t > 0.f ? s * t : -INFINITY;  // (NaN -> -inf as well)
+}
+
+struct StripFix {
+    const bf16_t* x;        // the encoder GEMM's A operand (bf16 rows of D elements) ...
+    const int32_t* arows;   // ... through its row list (nullable)
+    const bf16_t* We;       // [H][D] bf16
+    const float* bias;      // the folded encoder bias the GEMM added
+    int D;
+    float tg;               // the threshold the GEMM stored with (-inf: everything was stored)
+    uint32_t* tmin_group;   // this launch's group (nullable)
+    int32_t* miss_rows;     // rows that had to recompute strips, cumulative (statistics)
+};
+
+// this row's T: keep the batch minimum for the next launches' prediction.  One row in four reports (a minimum over a
+// quarter of the batch predicts as well, and the check below does not rely on it).
+__device__ __forceinline__ void strip_fix_note(const StripFix& f, uint32_t thi, int b, int lane) {
+    if (f.tmin_group && (b & 3) == 0 && lane == 0) atomicMin(f.tmin_group + ((b >> 2) & (TG_SLOTS - 1)) * TG_SLOT_STRIDE, thi);
+}
+
+// Recompute, into prow, the strips of one row named by `masks` (wave-private LDS: bit s & 31 of word s >> 5 = strip s is
+// wanted; nwords words).  xs: wave-private LDS for the row's x (2 D bytes), or null (D too large: x is read from memory).
+// Output row 0 of a 32 x 32 MFMA tile whose A rows all carry x[b]: lane (r, h) supplies k = 16 s + 8 h + j of both
+// operands at step s, as the GEMM's lanes do (Mfma256s<bf16_t>::slab, slabs and steps ascending in k), so the sums are the
+// GEMM's own.  W_e comes from L2 eight K steps at a time.
+typedef const __attribute__((address_space(1))) bf16x8* gptr_bf16x8;
+typedef __attribute__((address_space(3))) char* lds_bytes;
+
+template <bool XS>
+__device__ __noinline__ void strip_fix_fill(const bf16_t* xrow, const bf16_t* We, const float* bias, int D, int32_t* miss_rows,
+                                            int32_t* group_misses, const int* masks, int nwords, lds_bytes xs, float* prow, int lane) {
+    if (lane == 0) {
+        atomicAdd(miss_rows, 1);
+        atomicAdd(group_misses, 1);
+    }
+    const int r = lane & 31, h = lane >> 5;
+    gptr_bf16x8 ap = (gptr_bf16x8)(uintptr_t)(xrow + 8 * h);
+    if constexpr (XS) {
+        for (int c = lane; c < (D >> 3); c += 64) *(__attribute__((address_space(3))) bf16x8*)(xs + 16 * c) = *(gptr_bf16x8)(uintptr_t)(xrow + 8 * c);
+        __builtin_amdgcn_wave_barrier();
+    }
+    constexpr int NB = XS ? 8 : 4;  // K steps in flight (D is a multiple of 128 on the persistent GEMM's shapes)
+    for (int w = 0; w < nwords; ++w) {
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(masks[w]);
+        uint32_t pairs = (m | (m >> 1)) & 0x55555555u;  // 32-column blocks with a wanted strip
+        while (pairs) {
+            const int p = __builtin_ctz(pairs);
+            pairs &= pairs - 1;
+            const int blk = (32 * w + p) >> 1;
+            const bool n0 = (m >> p) & 1u, n1 = (m >> (p + 1)) & 1u;
+            gptr_bf16x8 bp = (gptr_bf16x8)(uintptr_t)(We + (int64_t)(blk * 32 + r) * D + 8 * h);
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int s0 = 0; s0 < (D >> 4); s0 += NB) {
+                bf16x8 bv[NB], av[XS ? 1 : NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    bv[j] = bp[2 * (s0 + j)];
+                    if constexpr (!XS) av[j] = ap[2 * (s0 + j)];
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if constexpr (XS) av[0] = *(const __attribute__((address_space(3))) bf16x8*)(xs + 32 * (s0 + j) + 16 * h);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[XS ? 0 : j], bv[j], acc, 0, 0, 0);
+                }
+            }
+            const float v = acc[0] + bias[blk * 32 + r];
+            if (h == 0 && (r < 16 ? n0 : n1)) prow[blk * 32 + r] = v;
+        }
+    }
+    __threadfence();  // the row is read back by this wave (and must not come from a stale L1 line)
+}
+
+// candidate strips (maximum ranks >= th) -> slist, their elements ranking >= th -> list; returns the number of such
+// elements (may exceed CAP: only CAP are stored), or -1 when more than TS_MAX_STRIPS strips qualify
+template <int SPL, int CAP>
+__device__ __forceinline__ int strips_collect(const float* row, const float (&sm)[SPL], int ns, uint32_t th, int lane,
+                                              uint64_t* list, int* slist) {
+    int nstr = 0;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const bool pass = lane + 64 * i < ns && f32_ord(sm[i]) >= th;
+        const unsigned long long mask = __ballot(pass);
+        const int pos = nstr + __popcll(mask & ((1ull << lane) - 1ull));
+        if (pass && pos < TS_MAX_STRIPS) slist[pos] = lane + 64 * i;
+        nstr += __popcll(mask);
+    }
+    if (nstr > TS_MAX_STRIPS) return -1;
+    __builtin_amdgcn_wave_barrier();
+    // read the candidate strips, 16 per pass: lane l -> strip slist[base + l / 4], float4 number l & 3
+    int total = 0;
+    for (int base = 0; base < nstr; base += 16) {
+        const int si = base + (lane >> 2);
+        const bool in = si < nstr;
+        const int s = in ? slist[si] : 0;
+        const int e = s * 16 + (lane & 3) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) v = *(const float4*)(row + e);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t o = f32_ord(vv[c]);
+            const bool pass = in && o >= th;
+            const unsigned long long mask = __ballot(pass);
+            if (mask) {
+                const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pass && pos < CAP) list[pos] = ((uint64_t)o << 32) | (uint32_t)(~(uint32_t)(e + c));
+                total += __popcll(mask);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return total;
+}
+
+// rebuild the strips of row b that the GEMM did not store (maximum < tg) and whose maximum ranks >= lo
+template <int SPL, int CAP>
+__device__ __forceinline__ void strips_refill(const StripFix& fix, int b, const float (&sm)[SPL], int ns, uint32_t lo, int lane,
+                                              uint64_t* list, int* slist, float* row) {
+    if (!(fix.tg > -INFINITY)) return;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        const bool want = lane + 64 * i < ns && sm[i] < fix.tg && f32_ord(sm[i]) >= lo;
+        const unsigned long long m = __ballot(want);
+        if (lane == 0) {
+            slist[2 * i] = (int)(uint32_t)m;
+            slist[2 * i + 1] = (int)(uint32_t)(m >> 32);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bf16_t* xrow = fix.x + (int64_t)(fix.arows ? fix.arows[b] : b) * fix.D;
+    if (fix.D <= 4 * CAP)  // the row's x fits the wave's candidate list (rebuilt afterwards)
+        strip_fix_fill<true>(xrow, fix.We, fix.bias, fix.D, fix.miss_rows, (int32_t*)fix.tmin_group + TG_HDR_MISSES, slist, 2 * SPL, (lds_bytes)(char*)list, row, lane);
+    else
+        strip_fix_fill<false>(xrow, fix.We, fix.bias, fix.D, fix.miss_rows, (int32_t*)fix.tmin_group + TG_HDR_MISSES, slist, 2 * SPL, nullptr, row, lane);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// (rare paths of topk_strips_row, out of line so that they cost the common path no registers)
+// The row's T is below the store threshold tg.  First select at tg itself: every element >= tg lives in a stored strip, so
+// when at least K of them turn up the K best are among them and nothing is missing after all (T is only a lower bound of
+// the K-th largest element - about 5 % below it on Gaussian rows).  Otherwise rebuild the strips with T <= maximum < tg.
+// full != 0: the exact path is wanted straight away (too many candidate strips or candidates at T).
+template <int SPL, int CAP>
+__device__ __noinline__ void topk_strips_row_rare(const float* row, const float* srow, int H, int K, int lane, uint64_t* list,
+                                                  int* slist, float* vrow, int32_t* irow, int32_t* fallback_rows, float* vs,
+                                                  int32_t* is, StripFix fix, int b, uint32_t thi, int full) {
+    const int ns = H >> 4;
+    float sm[SPL];
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) sm[i] = lane + 64 * i < ns ? srow[lane + 64 * i] : -INFINITY;
+    if (!full) {
+        int total = strips_collect<SPL, CAP>(row, sm, ns, f32_ord(fix.tg), lane, list, slist);
+        if (total >= 0 && total < K) {
+            strips_refill<SPL, CAP>(fix, b, sm, ns, thi, lane, list, slist, (float*)row);
+            total = strips_collect<SPL, CAP>(row, sm, ns, thi, lane, list, slist);
+        }
+        if (total >= K && total <= CAP) {
+            topk_emit_any<CAP>(list, total, K, lane, vrow, irow, vs, is);
+            return;
+        }
+    }
+    strips_refill<SPL, CAP>(fix, b, sm, ns, 0u, lane, list, slist, (float*)row);  // the exact path reads the whole row
+    topk_row_generic<CAP>(row, H, K, list, lane, vrow, irow, fallback_rows, vs, is);
+}
+
+// pred: the encoder GEMM stored this batch's strips selectively (see above), fix says how to rebuild one
 template <int SPL, int NTOP, int CAP>
-__device__ __forceinline__ void topk_strips_row(const float* __restrict__ row, const float* __restrict__ srow, int H,
+__device__ __forceinline__ void topk_strips_row(const float* row, const float* __restrict__ srow, int H,
                                                 int K, int lane, uint64_t* list, int* slist, float* vrow,
                                                 int32_t* irow, int32_t* fallback_rows, float* vs = nullptr,
-                                                int32_t* is = nullptr) {
+                                                int32_t* is = nullptr, bool pred = false, const StripFix& fix = StripFix(), int b = 0) {
     const int ns = H >> 4;
     float sm[SPL];
     float m = -INFINITY, m2 = -INFINITY;
@@ -219,48 +450,18 @@ __device__ __forceinline__ void topk_strips_row(const float* __restrict__ row, c
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)mk[1], (K - 1) >> 1);
         thi = ((K - 1) & 1) ? hi : lo;
     }
-
-    // candidate strips -> wave-private list (ballot prefix per i)
-    int nstr = 0;
-#pragma unroll
-    for (int i = 0; i < SPL; ++i) {
-        const bool pass = lane + 64 * i < ns && f32_ord(sm[i]) >= thi;
-        const unsigned long long mask = __ballot(pass);
-        const int pos = nstr + __popcll(mask & ((1ull << lane) - 1ull));
-        if (pass && pos < TS_MAX_STRIPS) slist[pos] = lane + 64 * i;
-        nstr += __popcll(mask);
-    }
-    if (nstr > TS_MAX_STRIPS) {
-        topk_row_generic<CAP>(row, H, K, list, lane, vrow, irow, fallback_rows, vs, is);
-        return;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // read the candidate strips, 16 per pass: lane l -> strip slist[base + l / 4], float4 number l & 3
-    int total = 0;
-    for (int base = 0; base < nstr; base += 16) {
-        const int si = base + (lane >> 2);
-        const bool in = si < nstr;
-        const int s = in ? slist[si] : 0;
-        const int e = s * 16 + (lane & 3) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) v = *(const float4*)(row + e);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t o = f32_ord(vv[c]);
-            const bool pass = in && o >= thi;
-            const unsigned long long mask = __ballot(pass);
-            if (mask) {
-                const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
-                if (pass && pos < CAP) list[pos] = ((uint64_t)o << 32) | (uint32_t)(~(uint32_t)(e + c));
-                total += __popcll(mask);
-            }
+    if (pred) {
+        strip_fix_note(fix, thi, b, lane);
+        if (!(ord_f32(thi) >= fix.tg)) {
+            topk_strips_row_rare<SPL, CAP>(row, srow, H, K, lane, list, slist, vrow, irow, fallback_rows, vs, is, fix, b, thi, 0);
+            return;
         }
     }
-    if (total > CAP || total < K) {
-        topk_row_generic<CAP>(row, H, K, list, lane, vrow, irow, fallback_rows, vs, is);
+    const int total = strips_collect<SPL, CAP>(row, sm, ns, thi, lane, list, slist);
+    if (total < 0 || total > CAP || total < K) {
+        if (pred) topk_strips_row_rare<SPL, CAP>(row, srow, H, K, lane, list, slist, vrow, irow, fallback_rows, vs, is, fix, b, thi, 1);
+        else topk_row_generic<CAP>(row, H, K, list, lane, vrow, irow, fallback_rows, vs, is);
         return;
     }
-    __builtin_amdgcn_wave_barrier();
     topk_emit_any<CAP>(list, total, K, lane, vrow, irow, vs, is);
 }

@@ -53,6 +53,8 @@ SIGNATURES = {
     "wsae_ctx_reserve_relu": (C.c_int, [_p]),
     "wsae_ctx_set_relu_fp8": (C.c_int, [_p, _i32]),
     "wsae_ctx_set_relu_l1_weights": (C.c_int, [_p, _p]),
+    "wsae_ctx_set_strip_predict": (C.c_int, [_p, _i32, C.c_float]),
+    "wsae_ctx_strip_stats": (C.c_int, [_p, _p, _p, _p]),
     "wsae_ctx_set_fired": (C.c_int, [_p, _p]),
     "wsae_prepare": (C.c_int, [_p, _p, _p]),
     "wsae_encode_topk": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
