@@ -211,11 +211,11 @@ __device__ __noinline__ void topk_row_generic(const float* row, int H, int K, ui
 // TG_S_UP per launch to at most TG_S_MAX - on data whose row thresholds scatter widely it settles low (at TG_S_MIN
 // hardly a strip is skipped and hardly a row can miss), on well-behaved data just below the batch minimum.
 // ------------------------------------------------------------------------------------------------
-#define TG_S_START 0.9f
+#define TG_S_START 0.95f
 #define TG_S_MAX 1.0f
 #define TG_S_MIN 0.25f
 #define TG_S_DOWN 0.9f
-#define TG_S_UP 0.002f
+#define TG_S_UP 0.005f
 
 // slots: three groups used in rotation; `cur` is the group of the current batch (its GEMM launch re-arms it, its TopK
 // launch fills it), the other two belong to the two batches before it.  A group: TG_SLOTS minimum words, TG_SLOT_STRIDE
