@@ -149,6 +149,45 @@ class TestCodeDoesNotDependOnThePrediction:
             v, i = code(m, x)
             assert torch.equal(i, ref_i) and torch.equal(v, ref_v), f"assumed minimum {assume}"
 
+    def test_fp32_input_goes_through_the_staged_copy(self, device):
+        """fp32 activations are staged to bf16 first: the recompute path must read that staged copy, not the caller's tensor."""
+        B = 2048
+        m = build(device)
+        x = batch(device, B, 51).float()
+        predict(m, B, False)
+        ref_v, ref_i = code(m, x)
+        predict(m, B, True, 1e30)
+        v, i = code(m, x)
+        assert torch.equal(i, ref_i) and torch.equal(v, ref_v)
+        assert stats(m, B)[0] >= B
+
+    def test_ring_rows_through_the_row_list(self, device, tmp_path):
+        """The trainer's ring batches reach the GEMM as a row list into the ring: one forced-recompute step equals the plain one."""
+        from whisper_sae.config import TrainingConfig
+        from whisper_sae.data import ActivationRing
+        from whisper_sae.sae.training import SAETrainer
+        B = 4096
+        out = []
+        for assume in (None, 1e30):
+            m = build(device, seed=9)
+            cfg = TrainingConfig(batch_size=B, learning_rate=1e-4, weight_decay=0.0, epochs=1, warmup_steps=0, gradient_clip=1.0,
+                                 use_amp=True, num_workers=0)
+            tr = SAETrainer(m, cfg, device=device, run_dir=tmp_path)
+            ring = ActivationRing(1 << 15, D, device=device, dtype=torch.bfloat16)
+            ring.fill_synthetic(1 << 15, seed=3)
+            if assume is None:
+                predict(m, B, False)
+            else:
+                predict(m, B, True, assume)
+            met = tr.train_step(ring.batch(B, 42, 0, 0))
+            torch.cuda.synchronize()
+            out.append((float(met.loss), {k: v.detach().float().cpu().numpy().copy() for k, v in m.state_dict().items()
+                                          if v.dtype.is_floating_point}, stats(m, B)[0]))
+        assert out[0][2] == 0 and out[1][2] >= B
+        assert out[0][0] == out[1][0]
+        for k in out[0][1]:
+            assert np.array_equal(out[0][1][k], out[1][1][k]), k
+
     def test_k64_two_maxima_per_lane(self, device):
         B = 2048
         m = build(device, k=64)
