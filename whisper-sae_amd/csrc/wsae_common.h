@@ -246,6 +246,17 @@ __device__ __forceinline__ bool grid_ticket(unsigned long long* t, unsigned payl
     return true;
 }
 
+// 16-byte load / store with the non-temporal hint: data used once, which should leave the Infinity Cache to what is used again
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store4(float4* p, const float4& a) {
+    f32x4 v;
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    __builtin_nontemporal_store(v, (f32x4*)p);
+}
+
 template <int DT>
 __device__ __forceinline__ float load_act(const void* p, int64_t i) {
     if (DT == WSAE_DT_BF16) return (float)((const bf16_t*)p)[i];

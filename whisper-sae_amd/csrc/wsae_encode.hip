@@ -282,16 +282,15 @@ encode_gemm256d_kernel(const T* __restrict__ xb, int64_t lda, const T* __restric
                         : "v"(va.x), "v"(va.y), "v"(va.z), "v"(va.w), "v"(vb.x), "v"(vb.y), "v"(vb.z), "v"(vb.w));
                     // (all four lanes of a quad hold the strip maximum and store it to the same word: a store costs the
                     // memory pipe the same with 16 lanes as with 64, and no exec switching is needed)
-#ifndef WSAE_EXP_NOSMAX
+                    // (NOT non-temporal: these 16-byte pieces stop being merged into lines on the way - the GEMM takes 12 us longer)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ma), r_sm, off_sm, q * row_sm, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mb), r_sm, off_sm, (q + 1) * row_sm, 0);
-#else
-                    asm volatile("" :: "v"(ma), "v"(mb));
-#endif
                     // the strip itself only when its maximum reaches the store threshold (wsae_topk.h, "strip store
                     // threshold"): the TopK reads nothing below it, and recomputes the strip in the rare row where it must
-                    if (!(ma < tg)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, va), r_pre, off_pre, q * row_pre, 0);
-                    if (!(mb < tg)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, vb), r_pre, off_pre, (q + 1) * row_pre, 0);
+                    // (non-temporal, aux bit 1: the strips are read once, by the TopK launch right behind, and must not push the
+                    // optimizer state out of the Infinity Cache - 3.5 us of the step, half of them in update_rows)
+                    if (!(ma < tg)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, va), r_pre, off_pre, q * row_pre, 2);
+                    if (!(mb < tg)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, vb), r_pre, off_pre, (q + 1) * row_pre, 2);
                 }
                 __builtin_amdgcn_wave_barrier();
                 EN_T(7)

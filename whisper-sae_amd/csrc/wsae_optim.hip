@@ -230,7 +230,7 @@ __device__ __forceinline__ void row_load(RowRegs<NI>& r, const float* __restrict
     for (int i = 0; i < NI; ++i) {
         const int64_t o = base + min(lane * 4 + 256 * i, D - 4);
         r.p[i] = *(const float4*)(P + o);
-        r.g[i] = *(const float4*)(G + o);
+        r.g[i] = nt_load4((const float4*)(G + o));  // (last use of the gradient)
         r.m[i] = *(const float4*)(M + o);
         r.v[i] = *(const float4*)(V + o);
     }

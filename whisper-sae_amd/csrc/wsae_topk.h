@@ -353,7 +353,7 @@ __device__ __forceinline__ int strips_collect(const float* row, const float (&sm
         const int s = in ? slist[si] : 0;
         const int e = s * 16 + (lane & 3) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) v = *(const float4*)(row + e);
+        if (in) v = nt_load4((const float4*)(row + e));  // (read once)
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -434,7 +434,7 @@ __device__ __forceinline__ void topk_strips_row(const float* row, const float* _
 #pragma unroll
     for (int i = 0; i < SPL; ++i) {
         const int s = lane + 64 * i;
-        sm[i] = s < ns ? srow[s] : -INFINITY;
+        sm[i] = s < ns ? __builtin_nontemporal_load(srow + s) : -INFINITY;
         m2 = fmaxf(m2, fminf(m, sm[i]));
         m = fmaxf(m, sm[i]);
     }

@@ -845,7 +845,7 @@ grad_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ db
                     const int jr = idx >= nc ? 1 : 0, cc = idx - jr * nc;
 #pragma unroll
                     for (int sp = 0; sp < NS; ++sp)  // splits past nsplit re-read the last one (weight 0)
-                        v[t][sp] = base[(jr * NS + min(sp, nsplit - 1)) * nc + cc];
+                        v[t][sp] = nt_load4(base + (jr * NS + min(sp, nsplit - 1)) * nc + cc);  // (last use of the slabs)
                 }
 #pragma unroll
                 for (int t = 0; t < TR; ++t) {
