@@ -359,7 +359,9 @@ int wsae_ctx_set_relu_fp8(wsae_ctx* ctx, int32_t on);
 /* 1 when wsae_relu_forward / wsae_relu_backward at batch size B read / write the dense fp32 `hidden` buffer, 0 when it is
  * optional (bf16 mode, whole 128-row groups, input_dim a multiple of 128, hidden_dim of 256: the hidden code then lives as
  * bf16 in the ctx workspace, written by the encoder GEMM's epilogue, and `hidden` may be NULL - a trainer that never looks at
- * it saves 4 B H bytes of stores per step; a non-NULL `hidden` still receives the fp32 copy). */
+ * it saves 4 B H bytes of stores per step; a non-NULL `hidden` still receives the fp32 copy).  Where this returns 0, `recon` is
+ * optional as well: the forward's residual pass already leaves g = 2 (recon - x) / (B cols) and the db_d partials for the
+ * backward of the same batch, which then needs no recon (a non-NULL `recon` still receives the fp32 reconstruction). */
 int wsae_relu_needs_hidden(const wsae_ctx* ctx, int32_t B);
 /* Per-feature weights w[hidden_dim] of the L1 term (device memory, caller-owned, must outlive the calls; NULL = all ones, the
  * default): the sparsity term of wsae_relu_forward becomes sum_b sum_s w[s] |hidden[b][s]| / (B H) and wsae_relu_backward adds

@@ -570,6 +570,7 @@ static int decode_launch(wsae_ctx* ctx, const float* params, const void* x, int3
                          float* vals, int32_t* idx, int32_t B, float* recon, int32_t want_bwd, float* dpre,
                          int64_t* last_activated, const int64_t* step_count, wsae_stats* stats, hipStream_t st) {
     const int bwd = want_bwd & 1, want_g32 = (want_bwd >> 1) & 1;
+    ctx->relu_g_B = 0;  // (gb / part_dbd are about to be this launch's)
     if (wsae_internal_decode_mfma_ok(ctx))
         return wsae_internal_decode_mfma(ctx, params, x, x_dtype, rows, vals, idx, B, recon, bwd, dpre, want_g32,
                                          last_activated, step_count, stats, st);

@@ -240,7 +240,7 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
                     if (ok) {
                         bf16x4 o;
                         o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
-                        *(bf16x4*)(e.out16 + (int64_t)m * e.ld16 + ncol) = o;
+                        __builtin_nontemporal_store(o, (bf16x4*)(e.out16 + (int64_t)m * e.ld16 + ncol));
                         if (e.c) *(float4*)(e.c + (int64_t)m * e.ldc + ncol) = v;
                         s_l1 += (v.x * w4.x + v.y * w4.y) + (v.z * w4.z + v.w * w4.w);
                         s_cnt += (float)((v.x > 0.f) + (v.y > 0.f) + (v.z > 0.f) + (v.w > 0.f));
@@ -285,7 +285,7 @@ gemm256x_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
                         d.w = ((hi >> (16 + j)) & 1u) ? v.w + e.l1 * w4.w : 0.f;
                         bf16x4 o;
                         o[0] = (bf16_t)d.x; o[1] = (bf16_t)d.y; o[2] = (bf16_t)d.z; o[3] = (bf16_t)d.w;
-                        *(bf16x4*)(e.out16 + (int64_t)m * e.ld16 + ncol) = o;
+                        __builtin_nontemporal_store(o, (bf16x4*)(e.out16 + (int64_t)m * e.ld16 + ncol));  // (read once, by the contraction behind)
                     }
                     csum.x += d.x; csum.y += d.y; csum.z += d.z; csum.w += d.w;
                 }

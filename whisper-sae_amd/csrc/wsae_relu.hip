@@ -261,13 +261,49 @@ relu_act_kernel(const float* __restrict__ pre, float* __restrict__ hidden, T* __
 // ---- residual: loss partials; in backward also g (contraction dtype, row-major into xb), gT, db_d partials ----
 // recon2 / recon_out (forward of the row-major-GEMM flow): the reconstruction arrives as two split-K slabs, their sum is
 // written to recon_out on the way
+// what the forward's last block needs to turn the partial sums into the loss (relu_fwd_finish_kernel's arguments)
+struct FwdFinish {
+    const float* part;
+    int nblk_act, nblk_res, nblk, B, cols, H;
+    float weight;
+    wsae_stats* stats;
+    float* sparsity_out;
+    float* scal;
+    unsigned long long* ticket;  // null: no finish in this launch
+};
+
+__device__ __forceinline__ void relu_fwd_finish(const FwdFinish& f, float* red) {
+    float s = 0.f, c = 0.f, l = 0.f;
+    for (int i = threadIdx.x; i < f.nblk_act; i += 256) {  // (left by the launch before this one)
+        s += f.part[i];
+        c += f.part[f.nblk + i];
+    }
+    for (int i = threadIdx.x; i < f.nblk_res; i += 256)
+        l += __hip_atomic_load(f.part + 2 * f.nblk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float ts = block_sum(s, red), tc = block_sum(c, red), tl = block_sum(l, red);
+    if (threadIdx.x == 0) {
+        const float sparsity = ts / ((float)f.B * (float)f.H);
+        const float mse = tl / ((float)f.B * (float)f.cols);
+        f.scal[0] = sparsity;
+        f.scal[1] = mse;
+        if (f.sparsity_out) *f.sparsity_out = sparsity;
+        if (f.stats) {
+            f.stats->loss = mse + f.weight * sparsity;
+            f.stats->l0 = tc / (float)f.B;
+            f.stats->reserved = __float_as_int(sparsity);  // TrainingMetrics: reconstruction = loss - weight * sparsity
+        }
+    }
+}
+
 template <typename T, int XDT, bool BWD>
 __global__ void __launch_bounds__(256)
 resid_kernel(const float* __restrict__ recon, const void* __restrict__ x, const int32_t* __restrict__ rows, int B, int D,
              int ldT, float scale, T* __restrict__ g_rm, T* __restrict__ gT, float* __restrict__ part_dbd,
-             float* __restrict__ part_loss, const float* __restrict__ recon2 = nullptr, float* __restrict__ recon_out = nullptr) {
+             float* __restrict__ part_loss, const float* __restrict__ recon2 = nullptr, float* __restrict__ recon_out = nullptr,
+             FwdFinish fin = FwdFinish()) {
     __shared__ float tile[64][65];
     __shared__ float red[8];
+    __shared__ int last_s;
     const int d0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
     const int q = threadIdx.x & 15, r16 = threadIdx.x >> 4;
     float loss = 0.f;
@@ -310,7 +346,19 @@ resid_kernel(const float* __restrict__ recon, const void* __restrict__ x, const 
         }
     }
     const float t = block_sum(loss, red);
-    if (threadIdx.x == 0) part_loss[blockIdx.y * gridDim.x + blockIdx.x] = t;
+    if (!fin.ticket) {
+        if (threadIdx.x == 0) part_loss[blockIdx.y * gridDim.x + blockIdx.x] = t;
+        return;
+    }
+    // the forward's loss in this launch: the last block to arrive sums the partials (same order as relu_fwd_finish_kernel)
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(part_loss + blockIdx.y * gridDim.x + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned unused;
+        last_s = grid_ticket(fin.ticket, 0u, &unused);
+    }
+    __syncthreads();
+    if (last_s) relu_fwd_finish(fin, red);
 }
 
 // ---- dpre = (dh + l1) * 1[hidden > 0] -> dpreT, db_e partials ----------------------------------------
@@ -398,10 +446,15 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ p
 // Both bias gradients in ONE launch with the rows of a column spread over the block (the form above walks a column's rows in
 // one thread: 17 us per call at B = 16384 for a few hundred KB).  Block = 64 columns x 4 row parts, every thread sums its
 // rows 8 loads at a time, the four part sums meet in LDS in fixed order.  Blocks [0, nb1) serve (part1, N1), the rest (part2, N2).
+// sq_out / ticket (nullable together): the last block to arrive adds the squares of both results as one more global-norm
+// partial (the results are then handed over as agent-scope stores; fixed summation order).
 __global__ void __launch_bounds__(256)
 colsum2_kernel(const float* __restrict__ part1, int nrows1, int N1, float* __restrict__ out1, int nb1,
-               const float* __restrict__ part2, int nrows2, int N2, float* __restrict__ out2, float* __restrict__ zero_n2) {
+               const float* __restrict__ part2, int nrows2, int N2, float* __restrict__ out2, float* __restrict__ zero_n2,
+               float* __restrict__ sq_out = nullptr, unsigned long long* __restrict__ ticket = nullptr) {
     __shared__ float s[4][64];
+    __shared__ float red[8];
+    __shared__ int last_s;
     const bool second = (int)blockIdx.x >= nb1;
     // (no pre-bias in this module: its gradient slot, N2 values, stays exactly 0 - written here instead of by a fill launch)
     if (second && zero_n2 && threadIdx.x < 64 && ((int)blockIdx.x - nb1) * 64 + (int)threadIdx.x < N2)
@@ -424,7 +477,31 @@ colsum2_kernel(const float* __restrict__ part1, int nrows1, int N1, float* __res
     }
     s[rp][c] = a;
     __syncthreads();
-    if (rp == 0 && n < N) out[n] = (s[0][c] + s[1][c]) + (s[2][c] + s[3][c]);
+    if (rp == 0 && n < N) {
+        const float t = (s[0][c] + s[1][c]) + (s[2][c] + s[3][c]);
+        if (ticket) __hip_atomic_store(out + n, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[n] = t;
+    }
+    if (!ticket) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned unused;
+        last_s = grid_ticket(ticket, 0u, &unused);
+    }
+    __syncthreads();
+    if (!last_s) return;
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < N1; i += 256) {
+        const float v = __hip_atomic_load(out1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sq = fmaf(v, v, sq);
+    }
+    for (int i = threadIdx.x; i < N2; i += 256) {
+        const float v = __hip_atomic_load(out2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sq = fmaf(v, v, sq);
+    }
+    const float t = block_sum(sq, red);
+    if (threadIdx.x == 0) *sq_out = t;
 }
 
 __global__ void __launch_bounds__(256)
@@ -699,16 +776,22 @@ int forward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, co
         WSAE_REQUIRE(wsae_internal_gemm256x(ctx, 0, 1, GX_EPI_PLAIN, ws.hid, H, ctx->WdT_bf16, D, B, D, H, 2, e2, st),
                      "wsae_relu_forward: decoder GEMM rejected B %d, D %d, H %d", B, D, H);
     }
+    // residual pass: recon = slab 0 + slab 1 (written out only when the caller wants it), loss partials - and already
+    // g = 2 (recon - x) / (B cols) as bf16 [B][D] + the db_d partials, which is everything the backward would re-read the
+    // 4 B D bytes of recon for: wsae_relu_backward of this batch finds them (relu_g_B) and launches no residual pass
     dim3 gr(ceil_div(D, 64), ceil_div(ldT, 64));
-    if (x_dtype == WSAE_DT_F32)
-        resid_kernel<bf16_t, WSAE_DT_F32, false><<<gr, 256, 0, st>>>(ctx->pre, x, rows, B, D, ldT, 0.f, nullptr, nullptr, nullptr,
-                                                                    ws.part + 2 * ws.nblk, ctx->pre + (int64_t)B * D, recon);
-    else
-        resid_kernel<bf16_t, WSAE_DT_BF16, false><<<gr, 256, 0, st>>>(ctx->pre, x, rows, B, D, ldT, 0.f, nullptr, nullptr, nullptr,
-                                                                     ws.part + 2 * ws.nblk, ctx->pre + (int64_t)B * D, recon);
+    const float scale = 2.0f / ((float)B * (float)ctx->loss_cols);
+    // ... and the loss: the launch's last block sums the partials (no finishing launch)
     const int nt1 = ceil_div(H, 256) * ceil_div(B, 256);
-    relu_fwd_finish_kernel<<<1, 256, 0, st>>>(ws.part, nt1, (int)(gr.x * gr.y), ws.nblk, B, ctx->loss_cols, H, weight, stats,
-                                              sparsity_out, ws.scal);
+    const FwdFinish fin = {ws.part, nt1, (int)(gr.x * gr.y), ws.nblk, B, ctx->loss_cols, H, weight, stats, sparsity_out, ws.scal,
+                           (unsigned long long*)(ctx->counters + 16 + 2 * TICKET_WORDS)};
+    if (x_dtype == WSAE_DT_F32)
+        resid_kernel<bf16_t, WSAE_DT_F32, true><<<gr, 256, 0, st>>>(ctx->pre, x, rows, B, D, ldT, scale, ctx->gb, nullptr, ctx->part_dbd,
+                                                                   ws.part + 2 * ws.nblk, ctx->pre + (int64_t)B * D, recon, fin);
+    else
+        resid_kernel<bf16_t, WSAE_DT_BF16, true><<<gr, 256, 0, st>>>(ctx->pre, x, rows, B, D, ldT, scale, ctx->gb, nullptr, ctx->part_dbd,
+                                                                    ws.part + 2 * ws.nblk, ctx->pre + (int64_t)B * D, recon, fin);
+    ctx->relu_g_B = B;
     WSAE_LAUNCH_CHECK();
     ctx->relu_x_B = B;
     return WSAE_OK;
@@ -721,13 +804,17 @@ int backward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
     const ReluWs ws = host_ws(ctx);
     const float scale = 2.0f / ((float)B * (float)ctx->loss_cols);
     dim3 gr(ceil_div(D, 64), ceil_div(ldT, 64));
-    // g = 2 (recon - x) / (B cols) as bf16 [B][D] (row-major: what both consumers read), db_d partials
-    if (x_dtype == WSAE_DT_F32)
-        resid_kernel<bf16_t, WSAE_DT_F32, true><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, scale, ctx->gb, nullptr, ctx->part_dbd,
-                                                                   ws.part + 2 * ws.nblk);
-    else
-        resid_kernel<bf16_t, WSAE_DT_BF16, true><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, scale, ctx->gb, nullptr, ctx->part_dbd,
-                                                                    ws.part + 2 * ws.nblk);
+    // g = 2 (recon - x) / (B cols) as bf16 [B][D] (row-major: what both consumers read), db_d partials: left by the
+    // forward's residual pass; recomputed from recon only when something else has used the buffers since
+    if (ctx->relu_g_B != B) {
+        WSAE_REQUIRE(recon, "wsae_relu_backward: the forward's residual gradient is gone and no recon was passed to rebuild it");
+        if (x_dtype == WSAE_DT_F32)
+            resid_kernel<bf16_t, WSAE_DT_F32, true><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, scale, ctx->gb, nullptr, ctx->part_dbd,
+                                                                       ws.part + 2 * ws.nblk);
+        else
+            resid_kernel<bf16_t, WSAE_DT_BF16, true><<<gr, 256, 0, st>>>(recon, x, rows, B, D, ldT, scale, ctx->gb, nullptr, ctx->part_dbd,
+                                                                        ws.part + 2 * ws.nblk);
+    }
     bf16_t* dpre = (bf16_t*)ws.hidT;  // [B][H] (the transposed-hidden buffer of the general path is free in this flow)
     GxEpi e3 = {};
     e3.out16 = dpre; e3.ld16 = H;
@@ -755,9 +842,10 @@ int backward_x(wsae_ctx* ctx, const float* params, const void* x, int x_dtype, c
         slab_sum8_kernel<<<nsq, 256, 0, st>>>(ctx->wg_slabs, slab_stride, nz, slab_stride / 4, grads, grads + ctx->off[4], D, ctx->part_sq);
     }
     const int nb1 = ceil_div(H, 64);
+    // (the squares of the two bias gradients - one more norm partial - by the launch's last block: no bias_sq launch)
     colsum2_kernel<<<nb1 + ceil_div(D, 64), 256, 0, st>>>(ws.colpart, B / 128, H, grads + ctx->off[2], nb1, ctx->part_dbd,
-                                                          ceil_div(B, 64), D, grads + ctx->off[3], grads + ctx->off[4]);
-    bias_sq_kernel<<<1, 1024, 0, st>>>(grads + ctx->off[2], H, grads + ctx->off[3], D, ctx->part_sq + nsq);
+                                                          ceil_div(B, 64), D, grads + ctx->off[3], grads + ctx->off[4],
+                                                          ctx->part_sq + nsq, (unsigned long long*)(ctx->counters + 16 + 4 * TICKET_WORDS));
     WSAE_LAUNCH_CHECK();
     ctx->n_sq_parts = nsq + 1;  // wsae_adamw_step(norm_from_wgrad = 1) sums these: no separate norm pass
     ctx->g_is_bf16 = 1;
@@ -871,15 +959,15 @@ extern "C" int wsae_relu_needs_hidden(const wsae_ctx* ctx, int32_t B) { return (
 extern "C" int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,
                                  int32_t B, float sparsity_weight, float* hidden, float* recon, wsae_stats* stats,
                                  float* sparsity_loss_out, void* stream) {
-    WSAE_REQUIRE(ctx && params && x && recon, "wsae_relu_forward: null argument");
+    WSAE_REQUIRE(ctx && params && x, "wsae_relu_forward: null argument");
     WSAE_REQUIRE(x_dtype == WSAE_DT_F32 || x_dtype == WSAE_DT_BF16, "wsae_relu_forward: unknown activation dtype %d", x_dtype);
     int rc = check_dims(ctx, B, "wsae_relu_forward");
     if (rc) return rc;
     WSAE_REQUIRE(ctx->relu_ws, "wsae_relu_forward: call wsae_ctx_reserve_relu(ctx) once after wsae_ctx_create");
     hipStream_t st = (hipStream_t)stream;
-    ctx->relu_x_B = 0;
+    ctx->relu_x_B = ctx->relu_g_B = 0;
     if (x_flow_ok(ctx, B)) return forward_x(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, stats, sparsity_loss_out, st);
-    WSAE_REQUIRE(hidden, "wsae_relu_forward: this shape needs the fp32 hidden buffer (only the row-major-GEMM flow runs without it)");
+    WSAE_REQUIRE(hidden && recon, "wsae_relu_forward: this shape needs the fp32 hidden and recon buffers (only the row-major-GEMM flow runs without them)");
     return ctx->prec == WSAE_PREC_BF16
                ? forward_t<bf16_t>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, stats, sparsity_loss_out, st)
                : forward_t<float>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, stats, sparsity_loss_out, st);
@@ -888,7 +976,7 @@ extern "C" int wsae_relu_forward(wsae_ctx* ctx, const float* params, const void*
 extern "C" int wsae_relu_backward(wsae_ctx* ctx, const float* params, const void* x, int32_t x_dtype, const int32_t* rows,
                                   int32_t B, float sparsity_weight, const float* hidden, const float* recon, float* grads,
                                   void* stream) {
-    WSAE_REQUIRE(ctx && params && x && recon && grads, "wsae_relu_backward: null argument");
+    WSAE_REQUIRE(ctx && params && x && grads, "wsae_relu_backward: null argument");
     WSAE_REQUIRE(x_dtype == WSAE_DT_F32 || x_dtype == WSAE_DT_BF16, "wsae_relu_backward: unknown activation dtype %d", x_dtype);
     int rc = check_dims(ctx, B, "wsae_relu_backward");
     if (rc) return rc;
@@ -896,7 +984,7 @@ extern "C" int wsae_relu_backward(wsae_ctx* ctx, const float* params, const void
     hipStream_t st = (hipStream_t)stream;
     // (the forward of this batch ran the row-major-GEMM flow: its bf16 hidden is still in the workspace)
     if (ctx->relu_x_B == B && x_flow_ok(ctx, B)) return backward_x(ctx, params, x, x_dtype, rows, B, sparsity_weight, recon, grads, st);
-    WSAE_REQUIRE(hidden, "wsae_relu_backward: the fp32 hidden of the forward is needed on this path");
+    WSAE_REQUIRE(hidden && recon, "wsae_relu_backward: the fp32 hidden and recon of the forward are needed on this path");
     return ctx->prec == WSAE_PREC_BF16
                ? backward_t<bf16_t>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, grads, st)
                : backward_t<float>(ctx, params, x, x_dtype, rows, B, sparsity_weight, hidden, recon, grads, st);

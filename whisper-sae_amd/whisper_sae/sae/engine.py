@@ -123,15 +123,16 @@ class SAEEngine:
         return w
 
     def relu_work(self, batch: int, handle: int = 0) -> dict:
-        """Scratch of one ReLU step.  ``hidden`` (dense fp32 [B, H]) is only allocated when the kernels need it
-        (``wsae_relu_needs_hidden``: the bf16 row-major-GEMM flow keeps the code as bf16 in the ctx workspace)."""
+        """Scratch of one ReLU step.  ``hidden`` (dense fp32 [B, H]) and ``recon`` (fp32 [B, D]) are only allocated when the
+        kernels need them (``wsae_relu_needs_hidden``: the bf16 row-major-GEMM flow keeps the code as bf16 in the ctx workspace
+        and hands the residual gradient from the forward to the backward itself)."""
         w = self._work.get(("relu", batch))
         if w is None:
             if len(self._work) > 4:
                 self._work.clear()
             need = True if not handle else bool(self.lib.wsae_relu_needs_hidden(handle, batch))
             w = {"hidden": torch.empty(batch, self.H, dtype=torch.float32, device=self.device) if need else None,
-                 "recon": torch.empty(batch, self.D, dtype=torch.float32, device=self.device)}
+                 "recon": torch.empty(batch, self.D, dtype=torch.float32, device=self.device) if need else None}
             self._work[("relu", batch)] = w
         return w
 

@@ -358,11 +358,11 @@ class SAETrainer:
         chunk, slot = self._records.next(eng.device)
         stats = chunk.dev.data_ptr() + slot * N.STATS_WORDS * 4
         weight = float(model.sparsity_weight)
-        hid = N.ptr(w["hidden"])  # NULL where the kernels keep the hidden code as bf16 in their own workspace
-        N.check(lib.wsae_relu_forward(handle, pk, x.data_ptr(), xd, rp, B, weight, hid,
-                                      w["recon"].data_ptr(), stats, 0, st), "wsae_relu_forward")
-        N.check(lib.wsae_relu_backward(handle, pk, x.data_ptr(), xd, rp, B, weight, hid,
-                                       w["recon"].data_ptr(), opt.grads.data_ptr(), st), "wsae_relu_backward")
+        # NULL where the kernels keep the hidden code as bf16 in their own workspace and pass the residual gradient on themselves
+        hid, rec = N.ptr(w["hidden"]), N.ptr(w["recon"])
+        N.check(lib.wsae_relu_forward(handle, pk, x.data_ptr(), xd, rp, B, weight, hid, rec, stats, 0, st), "wsae_relu_forward")
+        N.check(lib.wsae_relu_backward(handle, pk, x.data_ptr(), xd, rp, B, weight, hid, rec, opt.grads.data_ptr(), st),
+                "wsae_relu_backward")
         eng.generation += 1
         ddp = world()[1] > 1
         grad_scale = sync_gradients(opt.grads, self._exchange_dtype) if ddp else 1.0
