@@ -73,6 +73,24 @@ __global__ void __launch_bounds__(256) stage_batch_kernel(const void* __restrict
     }
 }
 
+// bf16 rows -> the contiguous bf16 batch, nothing else (no transposed copy, no pre-bias: the row-major-GEMM flow of the ReLU
+// path).  One 16-byte chunk per thread and pass, two passes in flight: a row-list entry and one load deep, where the tile
+// kernel above walks four dependent (row index, 8-byte load) pairs per thread (1-2 us of the ReLU step at B = 16384, D = 384).
+__global__ void __launch_bounds__(256) stage_rows_copy_kernel(const uint4* __restrict__ x, const int32_t* __restrict__ rows,
+                                                              uint4* __restrict__ xb, int64_t nchunks, int cpr,
+                                                              int64_t* __restrict__ step_count) {
+    if (step_count && blockIdx.x == 0 && threadIdx.x == 0) *step_count += 1;  // model.py:175
+    const int64_t i0 = (int64_t)blockIdx.x * 512 + threadIdx.x, i1 = i0 + 256;
+    const int64_t j0 = min(i0, nchunks - 1), j1 = min(i1, nchunks - 1);
+    const int b0 = (int)(j0 / cpr), b1 = (int)(j1 / cpr);
+    const int64_t r0 = rows ? (int64_t)rows[b0] : (int64_t)b0, r1 = rows ? (int64_t)rows[b1] : (int64_t)b1;
+    // (plain loads: the rows are read again by the residual pass)
+    const uint4 v0 = x[r0 * cpr + (j0 - (int64_t)b0 * cpr)];
+    const uint4 v1 = x[r1 * cpr + (j1 - (int64_t)b1 * cpr)];
+    if (i0 < nchunks) xb[i0] = v0;
+    if (i1 < nchunks) xb[i1] = v1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // encode_gemm256d_kernel: encode_gemm256p_kernel with both operands staged by LDS-DMA into the swizzled,
 // unpadded image (wsae_mfma.h): no staging registers, no ds_write pass, 8 one-KB pieces per wave and K step,
@@ -608,7 +626,11 @@ static int stage_batch(wsae_ctx* c, const float* params, const void* x, int x_dt
     dim3 sg(ceil_div(ldT, 64), ceil_div(D, 64));
     T* xT = want_xT ? (T*)c->xT : nullptr;
     WSAE_PROF_BEGIN(c, WSAE_K_STAGE_BATCH, st);
-    if (x_dtype == WSAE_DT_F32)
+    if (!want_xT && sizeof(T) == 2 && x_dtype == WSAE_DT_BF16 && D % 8 == 0) {
+        const int64_t nchunks = (int64_t)B * (D / 8);
+        stage_rows_copy_kernel<<<(unsigned)ceil_div64(nchunks, 512), 256, 0, st>>>((const uint4*)x, rows, (uint4*)c->xb, nchunks, D / 8,
+                                                                                 step_count);
+    } else if (x_dtype == WSAE_DT_F32)
         stage_batch_kernel<WSAE_DT_F32, T><<<sg, 256, 0, st>>>(x, rows, params + c->off[4], (T*)c->xb, xT, B, D, ldT, step_count);
     else
         stage_batch_kernel<WSAE_DT_BF16, T><<<sg, 256, 0, st>>>(x, rows, params + c->off[4], (T*)c->xb, xT, B, D, ldT, step_count);
