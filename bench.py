@@ -313,8 +313,8 @@ def main() -> None:
                                     f"TopKSAE {D_MODEL}->{HIDDEN} k={TOPK} train step, informational" if args.dims else
                                     "BASELINE.json configs[1]: TopKSAE 384->3072 k=32 train step") + ", synthetic "
                                    "activations resident in the HBM ring buffer" + ("" if world == 1 else
-                                   f" (configs[2]: DDP x{world}, RCCL all-reduce of the gradients on a {trainer.grad_exchange} wire "
-                                   f"in two halves, the first under the encoder half of the backward)"),
+                                   f" (configs[2]: DDP x{world}, one RCCL all-reduce per step of the gradients, the dead-feature "
+                                   f"indicators and the step's metric scalars on a {trainer.grad_exchange} wire, issued in stream order)"),
                        "batch_per_gpu": B, "global_batch": world * B, "ring_rows_per_gpu": args.ring_rows,
                        "lr": 1e-4, "clip": 1.0, "parallelism": f"dp{world}",
                        **({"grad_exchange": trainer.grad_exchange} if world > 1 else {})},

@@ -240,9 +240,20 @@ int wsae_input_grad(wsae_ctx* ctx, const float* params, const int32_t* idx, cons
 /* Data parallel: turn the SUMMED wire (layout above, P + hidden_dim elements of wire_dtype) into the fp32 buffer
  * `grads_ext` = [gradient pack in pack order | fired] that wsae_adamw_step reads, and leave the gradient part's
  * squared-norm partials in the ctx, so that the following wsae_adamw_step(norm_from_wgrad = 1, grad_scale = 1 / world)
- * needs no norm pass of its own.  metrics_sum (nullable): float[2] = the ranks' summed (loss, l0) of this step; then
- * stats->loss / stats->l0 are overwritten with their means over `world` ranks (the metric exchange is
- * two scalars, off the critical path). */
+ * needs no norm pass of its own.  metrics_sum: float[2] = the ranks' summed (loss, l0) of this step from an exchange of the
+ * caller's own (may be the loss / l0 words of `stats` themselves), or NULL = take them from the wire's metric elements (when
+ * wsae_ctx_set_wire_metrics named a source for them); stats->loss / stats->l0 are overwritten with their means over `world`
+ * ranks. */
+/* The step's two metric scalars ride on the wire as well (a separate 8-byte all-reduce costs a data-parallel step 16 us of
+ * stream hand-over on MI355X): behind the fired indicators the wire carries WSAE_WIRE_METRIC_SLOTS more elements, written by
+ * the reduction launch that writes the indicators from the two floats at `loss_l0` (device memory, e.g. the first two words
+ * of the step's wsae_stats record; NULL = zeros) - the loss as 40-bit fixed point (2^-24 resolution, range 65536) in ten
+ * base-16 digits, l0 as 32-bit fixed point (2^-16) in eight, one digit per element, a non-finite flag in the element after:
+ * digit sums over up to 16 ranks stay below 256 and are therefore EXACT in a bf16 all-reduce as well.
+ * wsae_grads_unpack_wire(metrics_sum = NULL) decodes them and writes the rank means into stats.  The wire is thus
+ * P + hidden_dim + WSAE_WIRE_METRIC_SLOTS elements long. */
+#define WSAE_WIRE_METRIC_SLOTS 24
+int wsae_ctx_set_wire_metrics(wsae_ctx* ctx, const float* loss_l0);
 int wsae_grads_unpack_wire(wsae_ctx* ctx, const void* wire, int32_t wire_dtype, float* grads_ext,
                            const float* metrics_sum, int32_t world, wsae_stats* stats, void* stream);
 int wsae_adamw_step(wsae_ctx* ctx, float* params, const float* grads, float* exp_avg,

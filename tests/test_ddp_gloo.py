@@ -117,7 +117,7 @@ def _oracle_wire(st, x_mine, mode, dtype):
     grads = pack(O.backward(st, x_mine, fwd, mode))
     fired = torch.from_numpy((st.last_activated == int(st.step_count)).astype(np.float32))
     st.last_activated = before  # the clock is merged from the summed indicators below
-    return pack_to_wire(torch.cat([grads, fired]), D, H, dtype), fwd
+    return pack_to_wire(torch.cat([grads, fired]), D, H, dtype, metrics=(float(fwd["loss"]), float(fwd["l0"]))), fwd
 
 
 def _unpack_grads(flat: torch.Tensor) -> dict:
@@ -128,13 +128,13 @@ def _unpack_grads(flat: torch.Tensor) -> dict:
 
 
 def _worker_wire(rank: int, world: int, port: int, out_dir: str, steps: int):
-    from whisper_sae.distributed import WireExchange, wire_offsets, wire_to_pack
+    from whisper_sae.distributed import WIRE_METRIC_SLOTS, WireExchange, decode_wire_metrics, wire_offsets, wire_to_pack
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         total, _ = N.pack_layout(D, H)
         wo = wire_offsets(D, H)
-        assert wo["total"] == total + H and wo["fired"] == total
+        assert wo["total"] == total + H + WIRE_METRIC_SLOTS and wo["fired"] == total and wo["metrics"] == total + H
         xs = synth.activations(steps * world * B, D, seed=3, stream=8, bf16=False).reshape(steps, world * B, D)
         for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
             w = synth.sae_weights(D, H, seed=3, bf16=False, b_pre_scale=0.05)
@@ -143,11 +143,17 @@ def _worker_wire(rank: int, world: int, port: int, out_dir: str, steps: int):
             for s in range(steps):
                 wire, fwd = _oracle_wire(st, xs[s, rank * B:(rank + 1) * B], "fp32", dtype)
                 ex = WireExchange()
-                met = torch.tensor([float(fwd["loss"]), float(fwd["l0"])])
-                ex.start(met)
-                ex.start(wire[:wo["split"]])   # the decoder half goes first ...
-                ex.start(wire[wo["split"]:])   # ... the rest follows (the trainer launches the encoder half in between)
+                if s % 2 == 0:                     # the two-half form ...
+                    ex.start(wire[:wo["split"]])   # the decoder half goes first ...
+                    ex.start(wire[wo["split"]:])   # ... the rest follows (the trainer launches the encoder half in between)
+                else:                              # ... and the default: one collective, in stream order
+                    ex.run(wire)
                 scale = ex.finish()
+                # the step's (loss, l0) came over the wire as digits: their sums are exact whatever the wire dtype
+                met = decode_wire_metrics(wire[wo["metrics"]:].float(), 1)
+                ref = torch.tensor([float(fwd["loss"]), float(fwd["l0"])], dtype=torch.float64)
+                dist.all_reduce(ref)
+                assert abs(met[0] - float(ref[0])) <= 1e-6 * world and abs(met[1] - float(ref[1])) <= 2e-5 * world, (met, ref)
                 flat = wire_to_pack(wire, D, H)
                 step_now = int(st.step_count)
                 st.last_activated = merge_clock(torch.from_numpy(st.last_activated), flat[total:], step_now).numpy()
@@ -156,7 +162,7 @@ def _worker_wire(rank: int, world: int, port: int, out_dir: str, steps: int):
                 O.train_step(st, xs[s, rank * B:(rank + 1) * B], 1e-3, "fp32", max_norm=1.0, reduced_grads=red)
                 # the step's own forward advanced the clock a second time: keep the exchange's view of it
                 st.step_count, st.last_activated = np.int64(st_step), st_last
-                losses.append(float(met[0]) * scale)
+                losses.append(met[0] * scale)
             np.savez(os.path.join(out_dir, f"{tag}_{rank}.npz"), W_e=st.W_e, W_d=st.W_d, b_e=st.b_e, b_d=st.b_d, b_pre=st.b_pre,
                      last=st.last_activated, losses=np.array(losses))
     finally:
@@ -204,3 +210,20 @@ def test_wire_layout_round_trip():
     assert wire[wo["W_dT"]] == flat[off[1]] and wire[wo["W_e"]] == flat[off[0]] and wire[wo["b_e"]] == flat[off[2]]
     assert wire[wo["fired"]] == flat[total] and wire.numel() == wo["total"]
     assert torch.equal(wire_to_pack(wire, D, H), flat)
+
+
+def test_wire_metric_digits_sum_exactly_in_bf16():
+    """(loss, l0) as base-16 digits: the digit sums of up to 16 ranks stay below 256, which bf16 holds exactly - summed in any
+    order, in bf16, they decode to the fp64 mean of the ranks' values to the fixed-point resolution."""
+    from whisper_sae.distributed import WIRE_METRIC_SLOTS, decode_wire_metrics, encode_wire_metrics
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 8, 16):
+        losses = rng.uniform(1e-4, 3.0, world) * rng.choice([1.0, 100.0], world)
+        l0s = rng.integers(0, 64 * 16384, world) / 16384.0
+        acc = torch.zeros(WIRE_METRIC_SLOTS, dtype=torch.bfloat16)
+        for r in rng.permutation(world):
+            acc = (acc + torch.tensor(encode_wire_metrics(float(losses[r]), float(l0s[r])), dtype=torch.bfloat16))  # bf16 adds
+        loss, l0 = decode_wire_metrics(acc.float(), world)
+        assert abs(loss - losses.mean()) <= 2.0 ** -24 and abs(l0 - l0s.mean()) <= 2.0 ** -16, (world, loss, losses.mean())
+    bad = torch.tensor(encode_wire_metrics(float("nan"), 1.0)) + torch.tensor(encode_wire_metrics(0.5, 1.0))
+    assert all(np.isnan(v) for v in decode_wire_metrics(bad, 2))

@@ -511,16 +511,17 @@ class TestDdpClock:
             def start(self, view):
                 self.views.append(view)
 
+            run = start  # (the in-stream collective of the single-launch backward: "summed" in finish() as well)
+
             def finish(self):
                 torch.cuda.synchronize()
+                from whisper_sae.distributed import WIRE_METRIC_SLOTS
                 for v in self.views:
-                    if v.numel() == 2:        # the metric pair (loss, l0)
-                        v *= 2.0
-                        continue
-                    P = v.numel() - H         # narrow inputs: ONE view = the whole wire [gradients | fired]
-                    seen["local"] = v[P:].clone()
-                    v[P:] += fired_other      # SUM over the two ranks
-                    v[:P] *= 2.0              # (both ranks hold this rank's gradients: sum = 2x, scale 1/2 below)
+                    P = v.numel() - H - WIRE_METRIC_SLOTS  # ONE view = the whole wire [gradients | fired | metric digits]
+                    seen["local"] = v[P:P + H].clone()
+                    v[P:P + H] += fired_other  # SUM over the two ranks
+                    v[:P] *= 2.0               # (both ranks hold this rank's gradients: sum = 2x, scale 1/2 below)
+                    v[P + H:] *= 2.0           # ... and this rank's metric digits
                 return 0.5
 
         monkeypatch.setattr(T, "world", lambda: (None, 2))

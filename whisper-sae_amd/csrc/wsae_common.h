@@ -122,6 +122,7 @@ struct wsae_ctx {
     int relu_x_B;         // batch size of the last ReLU forward that ran the row-major-GEMM flow (its bf16 hidden is in relu_ws); 0 = none
     int relu_g_B;         // ... and whose residual pass left g (gb) and the db_d partials for the backward; 0 = none
     float* fired;         // caller-owned [H] indicator buffer for the DDP dead-feature clock, or null
+    const float* wire_metrics;  // caller-owned (loss, l0) of the step, encoded behind the indicators on the wire, or null
     int n_dec_blocks;     // blocks used by the last decode launch (partials to reduce)
     int n_sq_parts;       // global-norm partials left in part_sq by the last wsae_weight_grads
     float* dbd2;          // [64][D] level-1 reduction of part_dbd

@@ -292,6 +292,12 @@ extern "C" int wsae_ctx_strip_stats(wsae_ctx* ctx, int64_t* refilled_rows, float
     return WSAE_OK;
 }
 
+extern "C" int wsae_ctx_set_wire_metrics(wsae_ctx* ctx, const float* loss_l0) {
+    WSAE_REQUIRE(ctx, "wsae_ctx_set_wire_metrics: null ctx");
+    ctx->wire_metrics = loss_l0;
+    return WSAE_OK;
+}
+
 extern "C" int wsae_ctx_set_loss_cols(wsae_ctx* ctx, int32_t cols) {
     WSAE_REQUIRE(ctx && cols >= 1 && cols <= ctx->D, "wsae_ctx_set_loss_cols: columns must be in [1, input_dim]");
     ctx->loss_cols = cols;

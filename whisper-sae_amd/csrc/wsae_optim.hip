@@ -27,8 +27,8 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
 template <typename WT>
 __global__ void __launch_bounds__(256) wire_unpack_kernel(const WT* __restrict__ wire, int64_t n8, int64_t p8, int64_t hd8,
                                                           float* __restrict__ out, float* __restrict__ part,
-                                                          const float* __restrict__ metrics_sum, float inv_world,
-                                                          wsae_stats* __restrict__ stats) {
+                                                          const float* metrics_sum, float inv_world, wsae_stats* stats,
+                                                          int metric_digits) {
     __shared__ float red[8];
     float a = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
@@ -52,8 +52,19 @@ __global__ void __launch_bounds__(256) wire_unpack_kernel(const WT* __restrict__
     const float t = block_sum(a, red);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
     if (metrics_sum && stats && blockIdx.x == 0 && threadIdx.x == 0) {  // mean over the ranks of the per-rank batch means
-        stats->loss = metrics_sum[0] * inv_world;
-        stats->l0 = metrics_sum[1] * inv_world;
+        const float s0 = metrics_sum[0], s1 = metrics_sum[1];  // (may BE the record's loss / l0 words: summed in place)
+        stats->loss = s0 * inv_world;
+        stats->l0 = s1 * inv_world;
+    }
+    if (metric_digits && stats && blockIdx.x == 0 && threadIdx.x == 0) {
+        // the digit sums behind the fired indicators (include/wsae.h): exact integers below 256 in either wire dtype
+        const WT* d = wire + 8 * n8;
+        double ql = 0.0, q0 = 0.0;
+        for (int i = 9; i >= 0; --i) ql = ql * 16.0 + (double)(float)d[i];
+        for (int i = 17; i >= 10; --i) q0 = q0 * 16.0 + (double)(float)d[i];
+        const bool bad = (float)d[18] > 0.f;
+        stats->loss = bad ? NAN : (float)(ql / 16777216.0 * (double)inv_world);
+        stats->l0 = bad ? NAN : (float)(q0 / 65536.0 * (double)inv_world);
     }
 }
 
@@ -68,12 +79,14 @@ extern "C" int wsae_grads_unpack_wire(wsae_ctx* ctx, const void* wire, int32_t w
     const int64_t n8 = n_total / 8;
     const int nparts = (int)min((int64_t)WSAE_MAX_PARTIALS, ceil_div64(n8, 256));
     hipStream_t st = (hipStream_t)stream;
+    const int digits = (!metrics_sum && ctx->wire_metrics) ? 1 : 0;  // (loss, l0) came over the wire itself
+    WSAE_REQUIRE(!digits || world <= 16, "wsae_grads_unpack_wire: the wire's metric digits are exact for at most 16 ranks (%d)", world);
     if (wire_dtype == WSAE_DT_BF16)
         wire_unpack_kernel<bf16_t><<<nparts, 256, 0, st>>>((const bf16_t*)wire, n8, ctx->P / 8, hd / 8, grads_ext, ctx->part_sq,
-                                                            metrics_sum, 1.f / (float)world, stats);
+                                                            metrics_sum, 1.f / (float)world, stats, digits);
     else
         wire_unpack_kernel<float><<<nparts, 256, 0, st>>>((const float*)wire, n8, ctx->P / 8, hd / 8, grads_ext, ctx->part_sq,
-                                                           metrics_sum, 1.f / (float)world, stats);
+                                                           metrics_sum, 1.f / (float)world, stats, digits);
     WSAE_LAUNCH_CHECK();
     ctx->n_sq_parts = nparts;
     return WSAE_OK;

@@ -768,6 +768,22 @@ struct GfOut {
     int64_t oWe, oWd, oBe, oBd, oBp, oFired;
 };
 
+// the step's (loss, l0) as exact-summable digits behind the fired indicators (include/wsae.h, WSAE_WIRE_METRIC_SLOTS):
+// element i of the 24: loss digits 0..9 (40-bit fixed point, 2^-24), l0 digits 10..17 (32-bit, 2^-16), 18 = non-finite flag
+__device__ __forceinline__ float wire_metric_digit(const float* __restrict__ m, int i) {
+    if (i >= 19 || !m) return 0.f;
+    const float loss = m[0], l0 = m[1];
+    const bool bad = !(fabsf(loss) <= 3.0e38f) || !(fabsf(l0) <= 3.0e38f);
+    if (i == 18) return bad ? 1.f : 0.f;
+    if (bad) return 0.f;
+    if (i < 10) {
+        const double q = fmin(fmax((double)loss, 0.0) * 16777216.0 + 0.5, 1099511627775.0);
+        return (float)(((unsigned long long)q >> (4 * i)) & 15ull);
+    }
+    const double q = fmin(fmax((double)l0, 0.0) * 65536.0 + 0.5, 4294967295.0);
+    return (float)(((unsigned long long)q >> (4 * (i - 10))) & 15ull);
+}
+
 template <typename OT>
 __device__ __forceinline__ void gf_store4(OT* p, const float4& a) {
     if constexpr (sizeof(OT) == 2) {
@@ -785,7 +801,8 @@ grad_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ db
                    const float* __restrict__ bpre, OT* __restrict__ out, GfOut o, int H, int D, float* __restrict__ part_sq,
                    int nrb, int row0, int nrows, int slab_row0, const TW* __restrict__ W, float* __restrict__ part,
                    int nblk_h, const float* __restrict__ part_dbd, int n_dec, float* __restrict__ dbd2,
-                   unsigned long long* __restrict__ ticket, int do_bias, const float* __restrict__ fired_src, int with_dbe) {
+                   unsigned long long* __restrict__ ticket, int do_bias, const float* __restrict__ fired_src, int with_dbe,
+                   const float* __restrict__ metrics_src = nullptr) {
     __shared__ float red[8];
     __shared__ float e_s[DBPRE_ROWS];
     __shared__ __attribute__((aligned(16))) float p_s[1024];  // row-part sums of a db_pre block (D <= 512: parts x D <= 1024)
@@ -876,6 +893,7 @@ grad_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ db
                 const int h = bid * per + i;
                 if (h < H) out[o.oFired + h] = (OT)fired_src[h];
             }
+            if (bid == 0 && tid < WSAE_WIRE_METRIC_SLOTS) out[o.oFired + H + tid] = (OT)wire_metric_digit(metrics_src, tid);
         }
         const float t = block_sum(sq, red);
         if (tid == 0) part_sq[bid] = t;
@@ -1114,7 +1132,8 @@ static void launch_grad_finish(wsae_ctx* ctx, const WgPlan& p, hipStream_t st, c
     unsigned long long* ticket = (unsigned long long*)(ctx->counters + 16 + 4 * TICKET_WORDS);
     const int grid = nrb + (do_bias ? nblk + DBD_L1 : 0);
 #define GF_ARGS ctx->wg_slabs, ctx->dbe_slab, p.nsplit, bpre, out, o, H, D, ctx->part_sq, nrb, row0, nrows, slab_row0, W, \
-                ctx->dbpre_part, nblk, ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2, ticket, do_bias, fired_src, 1
+                ctx->dbpre_part, nblk, ctx->part_dbd, ctx->n_dec_blocks, ctx->dbd2, ticket, do_bias, fired_src, 1, \
+                (fired_src ? ctx->wire_metrics : nullptr)
     if (p.nslots == WSAE_WGRAD_MAX_SPLIT) grad_finish_kernel<TW, FOLD, OT, WSAE_WGRAD_MAX_SPLIT><<<grid, 256, 0, st>>>(GF_ARGS);
     else grad_finish_kernel<TW, FOLD, OT, 2 * WSAE_WGRAD_MAX_SPLIT><<<grid, 256, 0, st>>>(GF_ARGS);
 #undef GF_ARGS

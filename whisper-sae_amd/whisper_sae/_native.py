@@ -56,6 +56,7 @@ SIGNATURES = {
     "wsae_ctx_set_strip_predict": (C.c_int, [_p, _i32, C.c_float]),
     "wsae_ctx_strip_stats": (C.c_int, [_p, _p, _p, _p]),
     "wsae_ctx_set_fired": (C.c_int, [_p, _p]),
+    "wsae_ctx_set_wire_metrics": (C.c_int, [_p, _p]),
     "wsae_prepare": (C.c_int, [_p, _p, _p]),
     "wsae_encode_topk": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p]),
     "wsae_encode_dense": (C.c_int, [_p, _p, _p, _i32, _p, _i32, _p, _p]),
@@ -180,3 +181,5 @@ def profile_read(handle: int) -> dict:
 def ptr(t) -> int:
     """Device (or host) address of a torch tensor, or NULL for None."""
     return 0 if t is None else t.data_ptr()
+
+WIRE_METRIC_SLOTS = 24  # include/wsae.h WSAE_WIRE_METRIC_SLOTS

@@ -84,6 +84,14 @@ class TrainingConfig(BaseModel):
                                                  "gradient; bf16 = half the bytes over xGMI, every rank's gradient rounded "
                                                  "once to bf16 and summed in bf16 (opt-in: it changes the step); auto = bf16 "
                                                  "when use_amp, fp32 otherwise")
+    ddp_overlap_halves: bool = Field(False,
+                                     description="data-parallel runs only: run the backward in two halves (decoder matrix, then "
+                                                 "encoder matrix + biases) so that the first half's all-reduce runs under the second "
+                                                 "half's contraction. Each half re-does the contraction's epilogue and doubles the "
+                                                 "split-K slabs: +86 us of kernels at 384->3072 / B = 16384 on MI355X "
+                                                 "(profiles/r03_ddp_structure.txt), so it pays only when one half's all-reduce takes "
+                                                 "longer than that - not over xGMI at these sizes; default off = one contraction "
+                                                 "launch, one collective")
     ddp_comm_reserve_cus: int = Field(24, ge=0, le=128,
                                       description="data-parallel runs only: compute units the encoder half of the backward leaves "
                                                   "free so that the all-reduce of the decoder half can run beside it (0 = none)")

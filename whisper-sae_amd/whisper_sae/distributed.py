@@ -67,23 +67,61 @@ def sync_gradients(flat: torch.Tensor, exchange_dtype: torch.dtype = torch.float
     return 1.0 / n
 
 
+WIRE_METRIC_SLOTS = 24  # include/wsae.h
+
+
 def wire_offsets(input_dim: int, hidden_dim: int) -> dict:
-    """Element offsets of the wire layout ``[dW_dT | dW_e | db_e | db_d | db_pre | fired]`` (``include/wsae.h``)."""
+    """Element offsets of the wire layout ``[dW_dT | dW_e | db_e | db_d | db_pre | fired | metric digits]``
+    (``include/wsae.h``)."""
     hd = input_dim * hidden_dim
+    fired = 2 * hd + hidden_dim + 2 * input_dim
     return {"W_dT": 0, "W_e": hd, "b_e": 2 * hd, "b_d": 2 * hd + hidden_dim, "b_pre": 2 * hd + hidden_dim + input_dim,
-            "fired": 2 * hd + hidden_dim + 2 * input_dim, "total": 2 * hd + 2 * hidden_dim + 2 * input_dim, "split": hd}
+            "fired": fired, "metrics": fired + hidden_dim, "total": fired + hidden_dim + WIRE_METRIC_SLOTS, "split": hd}
 
 
-def pack_to_wire(grads_ext: torch.Tensor, input_dim: int, hidden_dim: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    """``[pack order: dW_e | dW_dT | biases | fired]`` -> wire order, in ``dtype`` (what the reduction kernel writes)."""
+def encode_wire_metrics(loss: float, l0: float) -> list:
+    """Host restatement of the digits the reduction kernel writes behind the fired indicators: the loss as 40-bit fixed
+    point (2^-24) in ten base-16 digits, l0 as 32-bit fixed point (2^-16) in eight, a non-finite flag, zeros.  Sums of a
+    digit over up to 16 ranks stay below 256: exact in a bf16 all-reduce too."""
+    import math
+    d = [0.0] * WIRE_METRIC_SLOTS
+    if not (math.isfinite(loss) and math.isfinite(l0)):
+        d[18] = 1.0
+        return d
+    ql = min(int(max(loss, 0.0) * 16777216.0 + 0.5), (1 << 40) - 1)
+    q0 = min(int(max(l0, 0.0) * 65536.0 + 0.5), (1 << 32) - 1)
+    for i in range(10):
+        d[i] = float((ql >> (4 * i)) & 15)
+    for i in range(8):
+        d[10 + i] = float((q0 >> (4 * i)) & 15)
+    return d
+
+
+def decode_wire_metrics(digit_sums, world: int) -> tuple:
+    """``(mean loss, mean l0)`` from the summed digits (what ``wsae_grads_unpack_wire`` writes into the step record)."""
+    if float(digit_sums[18]) > 0:
+        return float("nan"), float("nan")
+    ql = sum(float(digit_sums[i]) * 16.0 ** i for i in range(10))
+    q0 = sum(float(digit_sums[10 + i]) * 16.0 ** i for i in range(8))
+    return ql / 16777216.0 / world, q0 / 65536.0 / world
+
+
+def pack_to_wire(grads_ext: torch.Tensor, input_dim: int, hidden_dim: int, dtype: torch.dtype = torch.float32,
+                 metrics: tuple = None) -> torch.Tensor:
+    """``[pack order: dW_e | dW_dT | biases | fired]`` -> wire order + the metric digits of ``metrics = (loss, l0)`` (zeros
+    when None), in ``dtype`` (what the reduction kernel writes)."""
     hd = input_dim * hidden_dim
-    return torch.cat([grads_ext[hd:2 * hd], grads_ext[:hd], grads_ext[2 * hd:]]).to(dtype)
+    tail = torch.tensor(encode_wire_metrics(*metrics) if metrics is not None else [0.0] * WIRE_METRIC_SLOTS,
+                        dtype=grads_ext.dtype, device=grads_ext.device)
+    return torch.cat([grads_ext[hd:2 * hd], grads_ext[:hd], grads_ext[2 * hd:], tail]).to(dtype)
 
 
 def wire_to_pack(wire: torch.Tensor, input_dim: int, hidden_dim: int) -> torch.Tensor:
-    """The summed wire back in pack order, fp32 (what ``wsae_grads_unpack_wire`` produces)."""
+    """The gradient / fired part of the summed wire back in pack order, fp32 (what ``wsae_grads_unpack_wire`` produces; the
+    metric digits are ``wire[wire_offsets(...)["metrics"]:]``, see ``decode_wire_metrics``)."""
     hd = input_dim * hidden_dim
-    return torch.cat([wire[hd:2 * hd], wire[:hd], wire[2 * hd:]]).float()
+    end = wire.numel() - WIRE_METRIC_SLOTS
+    return torch.cat([wire[hd:2 * hd], wire[:hd], wire[2 * hd:end]]).float()
 
 
 class WireExchange:
@@ -98,6 +136,15 @@ class WireExchange:
         dist, _ = world()
         if dist is not None:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def run(self, view: torch.Tensor) -> None:
+        """A collective with nothing to overlap: ``all_reduce(SUM)`` issued synchronously - the RCCL backend of this torch
+        then runs it on the CURRENT stream, in order with the kernels around it, instead of handing the data to its own
+        stream and back (two cross-queue waits: 20 us per step on MI355X, ``profiles/r03_ddp_structure.txt``); gloo blocks
+        the host until it is done."""
+        dist, _ = world()
+        if dist is not None:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=False)
 
     def finish(self) -> float:
         for wk in self._works:

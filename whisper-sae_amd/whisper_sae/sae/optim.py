@@ -43,14 +43,15 @@ class FusedAdamW(Optimizer):
         self.grads = self.grads_ext[:eng.P]
         self.fired = self.grads_ext[eng.P:]
         self._wire = None
-        self.metric_buf = torch.zeros(2, dtype=torch.float32, device=eng.device)  # (loss, l0) summed over the ranks under DDP
         self._alias_state(eng)
 
     def wire(self, dtype: torch.dtype) -> torch.Tensor:
-        """The data-parallel exchange buffer ``[dW_dT | dW_e | db_e | db_d | db_pre | fired]`` (include/wsae.h), P + H
-        elements of ``dtype``; allocated on first use, persistent so that asynchronous collectives may hold views of it."""
-        if self._wire is None or self._wire.dtype != dtype or self._wire.numel() != self.grads_ext.numel():
-            self._wire = torch.zeros(self.grads_ext.numel(), dtype=dtype, device=self.grads_ext.device)
+        """The data-parallel exchange buffer ``[dW_dT | dW_e | db_e | db_d | db_pre | fired | metric digits]``
+        (include/wsae.h), P + H + WSAE_WIRE_METRIC_SLOTS elements of ``dtype``; allocated on first use, persistent so that
+        asynchronous collectives may hold views of it."""
+        n = self.grads_ext.numel() + N.WIRE_METRIC_SLOTS
+        if self._wire is None or self._wire.dtype != dtype or self._wire.numel() != n:
+            self._wire = torch.zeros(n, dtype=dtype, device=self.grads_ext.device)
         return self._wire
 
     def _alias_state(self, eng) -> None:

@@ -303,17 +303,20 @@ class SAETrainer:
         return metrics
 
     def _ddp_backward(self, eng, handle, opt, x, xd, rp, w, B, chunk, slot, stats, st) -> float:
-        """Data-parallel backward (the reference is single-process): the weight gradients are
-        produced in two halves that land on the exchange buffer ("wire", include/wsae.h) directly, and each half's
-        all-reduce is started - asynchronously, on the process group's own stream - as soon as its half is there:
+        """Data-parallel backward (the reference is single-process).  Default: the single-process
+        backward with its reduction kernel writing the exchange buffer ("wire", include/wsae.h) instead of the gradient pack,
+        ONE all-reduce, one pass that turns the summed wire into the gradient pack + norm partials.  With
+        ``TrainingConfig.ddp_overlap_halves`` the weight gradients are produced in two halves that land on the wire, and each
+        half's all-reduce is started - asynchronously, on the process group's own stream - as soon as its half is there
+        (measured: the split costs more kernel time than an all-reduce over xGMI can give back at these sizes):
 
             decoder contraction + reduction -> wire[0, HD)      | all-reduce A starts
             encoder contraction + reduction + biases + fired -> wire[HD, P+H)   (A runs underneath)   | all-reduce B starts
             wait A, B -> one pass turns the summed wire into the fp32 gradient pack + norm partials -> optimizer
 
         ONE collective per half; only B (and what is left of A) is exposed.  The two metric scalars (loss, l0: per-rank
-        batch means) travel in a third, 8-byte all-reduce issued before the backward starts - off the critical path - and
-        their mean over the ranks replaces the local values in the step record.  No torch compute op: the wire is written
+        batch means) ride at the end of the wire as exact-summable digits (include/wsae.h) and their mean over the ranks
+        replaces the local values in the step record.  No torch compute op: the wire is written
         by the reduction kernel in its dtype (fp32, or bf16 = half the bytes; ``TrainingConfig.grad_exchange_dtype``).
         Returns the factor for the summed gradients (1 / world)."""
         dist, nranks = world()
@@ -322,13 +325,13 @@ class SAETrainer:
         wire = opt.wire(self._exchange_dtype)
         hd = eng.H * eng.D
         pk = eng.pack.data_ptr()
-        # metric scalars of this step (the decode launch has written them): summed over the ranks beside the gradients
-        met = opt.metric_buf
-        met.copy_(chunk.dev[slot].view(torch.float32)[:2], non_blocking=True)
+        # metric scalars of this step (the decode launch has written them into the step's record): the reduction kernel
+        # encodes them behind the fired indicators on the wire - digits whose sums are exact in bf16 as well - and the unpack
+        # pass writes their rank means back into the record: no collective of their own
+        N.check(lib.wsae_ctx_set_wire_metrics(handle, stats), "wsae_ctx_set_wire_metrics")
         ex = WireExchange()
-        ex.start(met)
         args = (handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(), w["dpre"].data_ptr(), B)
-        if lib.wsae_wgrad_parts_supported(handle):
+        if bool(getattr(self.config, "ddp_overlap_halves", False)) and lib.wsae_wgrad_parts_supported(handle):
             if getattr(self, "_reserve_set", None) != handle:  # once per ctx
                 N.check(lib.wsae_ctx_set_comm_reserve(handle, int(getattr(self.config, "ddp_comm_reserve_cus", 0))),
                         "wsae_ctx_set_comm_reserve")
@@ -337,12 +340,12 @@ class SAETrainer:
             ex.start(wire[:hd])
             N.check(lib.wsae_weight_grads_wire(*args, N.PART_ENCODER, wire.data_ptr(), wire_dt, st), "wsae_weight_grads_wire")
             ex.start(wire[hd:])
-        else:  # narrow inputs (one launch holds both contractions): one collective over the whole wire
+        else:  # the default (and narrow inputs, where one launch holds both contractions): one collective over the whole wire
             N.check(lib.wsae_weight_grads_wire(*args, N.PART_ALL, wire.data_ptr(), wire_dt, st), "wsae_weight_grads_wire")
-            ex.start(wire)
-        scale = ex.finish()  # (RCCL: the compute stream waits for the collectives; the host does not)
-        N.check(lib.wsae_grads_unpack_wire(handle, wire.data_ptr(), wire_dt, opt.grads_ext.data_ptr(), met.data_ptr(), nranks,
-                                           stats, st), "wsae_grads_unpack_wire")
+            ex.run(wire)  # (in stream order: nothing of this step could run beside it)
+        scale = ex.finish()  # (RCCL: the compute stream waits for the asynchronous collectives; the host does not)
+        N.check(lib.wsae_grads_unpack_wire(handle, wire.data_ptr(), wire_dt, opt.grads_ext.data_ptr(), 0, nranks, stats, st),
+                "wsae_grads_unpack_wire")
         return scale
 
     def _train_step_relu(self, model, eng, handle, opt, x, rows, B, prec) -> TrainingMetrics:
