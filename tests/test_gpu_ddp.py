@@ -176,5 +176,5 @@ def test_bench_rehearses_two_ranks_on_one_gpu(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["rehearsal"] is True and j["scaling"] == "weak"
     assert j["config"]["global_batch"] == 4096 and j["config"]["parallelism"] == "dp2"
-    assert j["config"]["grad_exchange"] == "bf16" and "two halves" in j["config"]["workload"]
+    assert j["config"]["grad_exchange"] == "bf16" and "one RCCL all-reduce per step" in j["config"]["workload"]
     assert j["value"] > 0 and np.isfinite(j["final_loss"])
