@@ -107,7 +107,7 @@ def kernel_work(name: str, B: int, D: int, H: int, K: int) -> dict:
 
 def roofline_object(name: str, n: int, ms: float, B: int, traffic_rec, launches_per_step: int = 1) -> dict:
     w = dict(kernel_work(name, B, D_MODEL, HIDDEN, TOPK))
-    if launches_per_step > 1:  # data parallel: the backward runs in two halves, each kernel's work splits evenly over its launches
+    if launches_per_step > 1:  # data parallel with ddp_overlap_halves: each kernel's work splits evenly over its two launches
         w["flops"] /= launches_per_step
         w["bytes"] /= launches_per_step
     t = ms / n * 1e-3

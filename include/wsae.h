@@ -192,16 +192,18 @@ int wsae_weight_grads(wsae_ctx* ctx, const float* params, const void* x, int32_t
 /* ---- data parallel: the gradients go straight onto the exchange buffer -------------------------------------------
  * (absent from the reference, which is single-process).  The WIRE is what the ranks
  * all-reduce(SUM): `hidden_dim * input_dim` elements of dW_dT, then dW_e, db_e, db_d, db_pre (the rest of the pack) and
- * the `hidden_dim` fired indicators of wsae_ctx_set_fired, P + hidden_dim elements of `wire_dtype` (WSAE_DT_F32: the exact
- * data-parallel gradient; WSAE_DT_BF16: half the bytes over xGMI, every rank's gradient rounded once to bf16, the
- * indicators - sums of at most world_size ones - exact).  The decoder matrix comes FIRST so that the two halves of the
- * backward fill two contiguous ranges:
+ * the `hidden_dim` fired indicators of wsae_ctx_set_fired, then WSAE_WIRE_METRIC_SLOTS metric digits (below): P + hidden_dim +
+ * WSAE_WIRE_METRIC_SLOTS elements of `wire_dtype` (WSAE_DT_F32: the exact data-parallel gradient; WSAE_DT_BF16: half the bytes
+ * over xGMI, every rank's gradient rounded once to bf16, the indicators - sums of at most world_size ones - and the digits
+ * exact).  Normally ONE call with part = WSAE_PART_ALL and one all-reduce.  The decoder matrix comes FIRST so that the
+ * optional two halves of the backward fill two contiguous ranges:
  *   part = WSAE_PART_DECODER  contraction of dW_dT alone (split-K 16) + its reduction -> wire[0, H D)
  *   part = WSAE_PART_ENCODER  contraction of dW_e alone + reduction + the three bias gradients + the indicators
  *                             -> wire[H D, P + H)          (same batch, after the decoder part)
  *   part = WSAE_PART_ALL      both contractions in one launch (the single-GPU geometry) -> the whole wire
- * The caller starts the all-reduce of wire[0, H D) after the decoder part, on its communication stream, and it runs under
- * the encoder part's contraction.  Halves need input_dim > 256 (wsae_wgrad_parts_supported); the gradient pack in
+ * With halves the caller starts the all-reduce of wire[0, H D) after the decoder part, on its communication stream, and it runs
+ * under the encoder part's contraction (measured on MI355X: the split costs +86 us of kernels and stream hand-overs per step
+ * against +16 us for WSAE_PART_ALL with one in-stream collective - DESIGN.md section 6).  Halves need input_dim > 256 (wsae_wgrad_parts_supported); the gradient pack in
  * `grads` form is NOT written by these calls: wsae_grads_unpack_wire produces it from the summed wire. */
 #define WSAE_PART_ALL (-1)
 #define WSAE_PART_DECODER 0

@@ -9,13 +9,15 @@ ROCm (xGMI inside a node); ``"gloo"`` runs the same code on CPU tensors for test
 The exchange buffer (the "wire", ``include/wsae.h``) is ``[dW_dT | dW_e | db_e | db_d | db_pre | fired]``, fp32 (the exact
 data-parallel gradient; the default) or bf16 (``TrainingConfig.grad_exchange_dtype = "bf16"``: half the bytes over xGMI);
 9.45 MB + 12 KB as fp32 at 384->3072.  The reduction kernel of the backward writes it directly - the decoder matrix first -
-and the trainer all-reduces it in TWO collectives, ``wire[:H D]`` as soon as the decoder half of the backward is done
-(it runs under the encoder half's contraction) and the rest after the encoder half (``SAETrainer._ddp_backward``); the
-1/world factor is folded into the fused optimizer kernel as ``grad_scale``.  ``fired[f]`` is 1.0 on the ranks where
+and the trainer all-reduces it in ONE collective issued in stream order (``SAETrainer._ddp_backward``; with
+``TrainingConfig.ddp_overlap_halves`` in two: ``wire[:H D]`` as soon as the decoder half of the backward is done, under the
+encoder half's contraction, and the rest after it); the 1/world factor is folded into the fused optimizer kernel as
+``grad_scale``.  ``fired[f]`` is 1.0 on the ranks where
 feature f fired in this step; its sum tells every rank which ``feature_last_activated`` entries to stamp with the current
 step, which equals an ``all_reduce(MAX)`` of the clocks (clocks that agreed before the step either all advance to the step
-or all stay) without another latency-bound collective.  The two metric scalars (loss, l0) are summed in an 8-byte
-collective of their own, issued before the backward: off the critical path.
+or all stay) without another latency-bound collective.  The two metric scalars (loss, l0) ride behind the indicators as
+base-16 digits of their fixed-point values (``encode_wire_metrics``): digit sums of up to 16 ranks stay below 256 and are
+exact in bf16 as well, so they need no collective of their own.
 
 ``WireExchange`` / ``pack_to_wire`` / ``wire_to_pack`` restate the host side of that protocol on plain tensors (CPU tests
 run it over gloo with oracle gradients; the trainer runs the same calls between its kernel launches).
