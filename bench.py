@@ -280,7 +280,7 @@ def main() -> None:
 
         if headline:
             names = dict(prof)
-            halves = 2 if (world > 1 and N.lib().wsae_wgrad_parts_supported(handle)) else 1
+            halves = 2 if (world > 1 and cfg.ddp_overlap_halves and N.lib().wsae_wgrad_parts_supported(handle)) else 1
 
             def lps(name):
                 return halves if name in ("wgrad", "wgrad_reduce") else 1
