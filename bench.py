@@ -192,7 +192,7 @@ def main() -> None:
     ring = ActivationRing(args.ring_rows, D_MODEL, device=device, dtype=ring_dtype)
     ring.fill_synthetic(args.ring_rows, seed=42 + rank)  # every rank owns its own shard of rows
     loader = RingLoader(ring, B, shuffle=True, seed=42)
-    total = args.warmup + (args.windows + 1) * args.steps + 8
+    total = args.warmup + (args.windows + 1) * args.steps + 8 + 224
     trainer.setup_scheduler(max(total, 20000))
 
     def batches():
@@ -217,8 +217,15 @@ def main() -> None:
     # launch (recorded by the library on the launch stream) ranks the step's kernels by average duration; the timed
     # windows then carry events around that kernel only (two event records per step).
     probe = {}
+    n_settle = n_probe = 0
     if not args.profile_all:
+        # (the ranking is only meaningful at the clock the timed windows run at: an idle GPU needs ~100 steps to get there, so
+        # with a short --warmup the probe is preceded by enough plain steps to make 200 untimed steps in all; the line reports
+        # every untimed step)
         n_probe = 24
+        n_settle = max(0, 200 - args.warmup - n_probe)
+        for _ in range(n_settle):
+            trainer.train_step(next(it))
         N.check(N.lib().wsae_profile_enable(handle, -1, n_probe), "wsae_profile_enable")
         for _ in range(n_probe):
             trainer.train_step(next(it))
@@ -322,6 +329,7 @@ def main() -> None:
             "roofline": roof,
             "roofline_wgrad2": roof_wgrad,
             "probe_kernel_us": {k: round(v[1] / max(v[0], 1) * 1e3, 2) for k, v in probe.items()},
+            "untimed_steps_before_windows": {"warmup": args.warmup, "settle": n_settle, "probe": n_probe},
             "step_dense_equiv_frac": value * f_dense / 1e12 / BF16_DENSE_PEAK_TFLOPS,
             "final_loss": last.loss if last is not None else None,
         }
