@@ -188,6 +188,33 @@ class TestCodeDoesNotDependOnThePrediction:
         for k in out[0][1]:
             assert np.array_equal(out[0][1][k], out[1][1][k]), k
 
+    @pytest.mark.parametrize("d,h,k,B", [(1280, 4096, 32, 2048),    # x row too long for the wave's LDS list: operands from memory
+                                         (256, 16384, 64, 2048),    # 1024 strips per row (16 maxima per lane), two thresholds per lane
+                                         (512, 2048, 16, 2304),     # 128 strips per row, the smallest the strip TopK takes
+                                         (384, 3072, 32, 2048 + 272)])  # a ragged last tile (stores everything) beside full ones
+    def test_other_shapes(self, device, d, h, k, B):
+        from whisper_sae.sae.model import TopKSAE
+        w = synth.sae_weights(d, h, seed=13, bf16=False, b_pre_scale=0.1)
+        m = TopKSAE(d, h, k=k, precision="bf16")
+        sd = m.state_dict()
+        for key in ("encoder.weight", "encoder.bias", "decoder.weight", "decoder.bias", "b_pre"):
+            sd[key] = torch.from_numpy(w[key])
+        m.load_state_dict(sd)
+        m = m.to(device)
+        xs = [torch.from_numpy(synth.activations(B, d, seed=60 + i, stream=0, bf16=True)).to(device=device, dtype=torch.bfloat16)
+              for i in range(2)]
+        predict(m, B, False)
+        ref_v, ref_i = code(m, xs[1])
+        predict(m, B, True)
+        code(m, xs[0])
+        _, tmin, _ = stats(m, B)
+        v, i = code(m, xs[1])
+        assert torch.equal(i, ref_i) and torch.equal(v, ref_v), "own history"
+        for assume in (1e30, 1.3 * tmin if tmin == tmin else 1.0):
+            predict(m, B, True, assume)
+            v, i = code(m, xs[1])
+            assert torch.equal(i, ref_i) and torch.equal(v, ref_v), f"assumed threshold {assume}"
+
     def test_k64_two_maxima_per_lane(self, device):
         B = 2048
         m = build(device, k=64)
