@@ -29,7 +29,8 @@ pytestmark = pytest.mark.gpu
 LR = 1e-3
 KEYS = ("encoder.weight", "encoder.bias", "decoder.weight", "decoder.bias", "b_pre")
 # small: narrow inputs -> one contraction launch, ONE collective over the whole wire;  cfg2: BASELINE.json configs[1] / [2]
-# dimensions at 2048 rows per rank -> the backward in two halves, two collectives, the first under the encoder half
+# dimensions at 2048 rows per rank, in the default form (one launch, one collective) and with ddp_overlap_halves (the backward
+# in two halves, two collectives, the first under the encoder half)
 CASES = {"small": dict(D=64, H=256, K=8, B=32, STEPS=4, resample_rows=200, resample_batch=48),
          "cfg2": dict(D=384, H=3072, K=32, B=2048, STEPS=4, resample_rows=2048, resample_batch=1024)}
 D = H = K = B = STEPS = None
@@ -42,7 +43,7 @@ def _use(case: str) -> dict:
     return c
 
 
-def _make(device, run_dir, use_amp, exchange="fp32", case="small"):
+def _make(device, run_dir, use_amp, exchange="fp32", case="small", halves=False):
     c = _use(case)
     from whisper_sae.config import TrainingConfig
     from whisper_sae.sae.model import TopKSAE
@@ -54,7 +55,7 @@ def _make(device, run_dir, use_amp, exchange="fp32", case="small"):
         sd[key] = torch.from_numpy(w[key])
     m.load_state_dict(sd)
     cfg = TrainingConfig(batch_size=B, learning_rate=LR, weight_decay=0.0, epochs=1, warmup_steps=0,
-                         gradient_clip=1.0, use_amp=use_amp, num_workers=0, grad_exchange_dtype=exchange)
+                         gradient_clip=1.0, use_amp=use_amp, num_workers=0, grad_exchange_dtype=exchange, ddp_overlap_halves=halves)
     tr = SAETrainer(m, cfg, device=device, run_dir=run_dir, resample_dead_every=2, resample_batch_size=c["resample_batch"],
                     resample_dead=True)
     return m, tr, w
@@ -76,7 +77,7 @@ def _dump(m, tr, mets, path):
     np.savez(path, **out)
 
 
-def _worker(rank: int, world: int, port: int, out_dir: str, use_amp: bool, exchange: str, case: str):
+def _worker(rank: int, world: int, port: int, out_dir: str, use_amp: bool, exchange: str, case: str, halves: bool = False):
     import torch.distributed as dist
     from torch.utils.data import TensorDataset
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -84,7 +85,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str, use_amp: bool, excha
     try:
         torch.cuda.set_device(0)
         torch.manual_seed(5)
-        m, tr, _ = _make("cuda:0", os.path.join(out_dir, "run"), use_amp, exchange, case)  # every rank is handed the same run_dir
+        m, tr, _ = _make("cuda:0", os.path.join(out_dir, "run"), use_amp, exchange, case, halves)  # every rank is handed the same run_dir
         tr.set_resample_dataset(TensorDataset(_resample_rows(rank, case)))  # ... and owns a different shard of rows
         xs = synth.activations(STEPS * world * B, D, seed=3, stream=8, bf16=False).reshape(STEPS, world * B, D)
         mets = []
@@ -106,14 +107,15 @@ def _free_port() -> int:
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("case,use_amp,exchange", [("small", False, "fp32"), ("small", True, "bf16"), ("cfg2", True, "bf16"),
-                                                   ("cfg2", True, "fp32")])
-def test_two_ranks_equal_the_single_process_step(device, tmp_path, case, use_amp, exchange):
+@pytest.mark.parametrize("case,use_amp,exchange,halves", [("small", False, "fp32", False), ("small", True, "bf16", False),
+                                                          ("cfg2", True, "bf16", False), ("cfg2", True, "fp32", False),
+                                                          ("cfg2", True, "bf16", True), ("cfg2", True, "fp32", True)])
+def test_two_ranks_equal_the_single_process_step(device, tmp_path, case, use_amp, exchange, halves):
     import torch.multiprocessing as mp
     from torch.utils.data import TensorDataset
     world = 2
     _use(case)
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_amp, exchange, case), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_amp, exchange, case, halves), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for key in r0.files:  # (loss / l0 included: the metric pair is averaged over the ranks in the step record)
         assert np.array_equal(r0[key], r1[key]), f"ranks disagree on {key}"
