@@ -267,7 +267,8 @@ struct Mfma96<bf16_t, MI> {
     //             lane's column (lane 4 q + p of a 16-lane group addresses block row q, columns 4 p .. 4 p + 3).
     // ARM = true: As too is a row-major image [feature block of 64][64 k rows][128 bytes] (the dense left operand of the
     //             ReLU SAE's contractions, wgrad2d_kernel): A fragments by transposed reads as well.
-    template <bool RM = false, bool ARM = false, typename F>
+    // PIPE = true : the four K steps as a software pipeline (below)
+    template <bool RM = false, bool ARM = false, bool PIPE = false, typename F>
     static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
                                                 f32x16 (&acc)[MI][3], F&& between) {
         const int r = lane & 31, h = lane >> 5;
@@ -297,36 +298,63 @@ struct Mfma96<bf16_t, MI> {
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) tpa[mi][q2] = rm_addr(As, a_row0 + mi * 32, q2);
         }
+        auto load_a = [&](int kk, int i) -> bf16x8 {
+            if constexpr (ARM) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tpa[i][0] + kk * 2048));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tpa[i][1] + kk * 2048));
+                return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+                return *(const bf16x8*)(ap + i * 32 * SWZ_ROW_BYTES + (((kk * 2 + h) ^ sw) << 4));
+            }
+        };
+        auto load_b = [&](int kk, int i) -> bf16x8 {
+            if constexpr (RM) {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tp[i][0] + kk * 2048));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tp[i][1] + kk * 2048));
+                return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+                return *(const bf16x8*)(bp + i * 32 * SWZ_ROW_BYTES + (((kk * 2 + h) ^ sw) << 4));
+            }
+        };
+        if constexpr (PIPE) {
+        // Software pipeline over the four K steps: the column fragments roll (b[ni] is reloaded for the next step as soon as its
+        // MI MFMAs of this step are issued), the row fragments of the next step are requested behind the last column group -
+        // all of it in front of between(kk), whose asm would otherwise keep every read of step kk + 1 behind it
+        bf16x8 a[MI], b[3];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = load_a(0, i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b[i] = load_b(0, i);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int co = ((kk * 2 + h) ^ sw) << 4;
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                if (kk < 3) b[ni] = load_b(kk + 1, ni);
+            }
+            if (kk < 3) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = load_a(kk + 1, i);
+                between(kk);
+            }
+        }
+        } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
             bf16x8 a[MI], b[3];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if constexpr (ARM) {
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tpa[i][0] + kk * 2048));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tpa[i][1] + kk * 2048));
-                    a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                } else {
-                    a[i] = *(const bf16x8*)(ap + i * 32 * SWZ_ROW_BYTES + co);
-                }
-            }
+            for (int i = 0; i < MI; ++i) a[i] = load_a(kk, i);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if constexpr (RM) {
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tp[i][0] + kk * 2048));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(tp[i][1] + kk * 2048));
-                    b[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                } else {
-                    b[i] = *(const bf16x8*)(bp + i * 32 * SWZ_ROW_BYTES + co);
-                }
-            }
+            for (int i = 0; i < 3; ++i) b[i] = load_b(kk, i);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 3; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
             if (kk < 3) between(kk);
+        }
         }
     }
     // row sums of the 16-row tile at row0 (+= over the chunk), every column of rs holds them
@@ -348,7 +376,7 @@ struct Mfma96<bf16_t, MI> {
 // same k permutation, so the contraction is unchanged.
 template <int MI>
 struct Mfma96<float, MI> {
-    template <bool RM = false, bool ARM = false, typename F>
+    template <bool RM = false, bool ARM = false, bool PIPE = false, typename F>  // (PIPE: accepted, not used)
     static __device__ __forceinline__ void slab(const char* As, const char* Bs, int a_row0, int b_row0, int lane,
                                                 f32x16 (&acc)[MI][3], F&& between) {
         static_assert(!RM && !ARM, "row-major dense operands need 16-bit transposed LDS reads: bf16 only");

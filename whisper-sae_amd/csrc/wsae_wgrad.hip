@@ -552,7 +552,7 @@ wgrad2_kernel(const uint32_t* __restrict__ ent_pos, const T* __restrict__ ent_hi
         entries(min(ck + 1, c_end - 1));  // (the last iteration re-reads its own chunk: keeps p_* = this chunk)
         if constexpr (RM) rm_use();       // row pointer of chunk ck + 1 (its list entry was requested a chunk ago)
         // (one call site: two copies of the MFMA phase made hipcc double the accumulators and spill)
-        Mfma96<T, W2_MI>::template slab<RM, false>(cur, cur + W2_A_BYTES, wm * 32 * W2_MI, wn * 96, lane, acc, [&](int kk) {
+        Mfma96<T, W2_MI>::template slab<RM, false, RM>(cur, cur + W2_A_BYTES, wm * 32 * W2_MI, wn * 96, lane, acc, [&](int kk) {
             if (more && kk < 2) dma3(ck + 1, buf ^ 1, kk * (W2_PIECES / 2));  // >= half a phase to land
             if constexpr (RM) {
                 if (kk == 2) rm_row(min(ck + 2, c_end - 1));  // the row list entry of the chunk after next (an L2 hit by then)
@@ -688,7 +688,8 @@ wgrad2d_kernel(const bf16_t* __restrict__ hid, const bf16_t* __restrict__ dpre, 
         const int buf = (ck - c_begin) & 1;
         char* cur = smem + buf * W2_STAGE;
         const bool more = ck + 1 < c_end;
-        Mfma96<bf16_t, W2_MI>::template slab<true, true>(cur, cur + W2_A_BYTES, wm * 32 * W2_MI, wn * 96, lane, acc, [&](int kk) {
+        Mfma96<bf16_t, W2_MI>::template slab<true, true>(  // (the pipelined form gains nothing here: the launch waits for its left operands from HBM)
+            cur, cur + W2_A_BYTES, wm * 32 * W2_MI, wn * 96, lane, acc, [&](int kk) {
             if (more) dma(ck + 1, buf ^ 1, kk);  // (kk = 0, 1, 2: the three parts)
         });
         dma_wait();       // issued during this chunk's MFMA phase: landed
