@@ -328,8 +328,13 @@ class SAETrainer:
         # metric scalars of this step (the decode launch has written them into the step's record): the reduction kernel
         # encodes them behind the fired indicators on the wire - digits whose sums are exact in bf16 as well - and the unpack
         # pass writes their rank means back into the record: no collective of their own
-        N.check(lib.wsae_ctx_set_wire_metrics(handle, stats), "wsae_ctx_set_wire_metrics")
+        digits = nranks <= 16  # (digit sums stay below 256 - exact in bf16 - for up to 16 ranks; beyond: a collective of their own)
+        N.check(lib.wsae_ctx_set_wire_metrics(handle, stats if digits else 0), "wsae_ctx_set_wire_metrics")
         ex = WireExchange()
+        met = None
+        if not digits:
+            met = chunk.dev[slot].view(torch.float32)[:2]  # summed in place in the step's record
+            ex.start(met)
         args = (handle, pk, x.data_ptr(), xd, rp, w["vals"].data_ptr(), w["idx"].data_ptr(), w["dpre"].data_ptr(), B)
         if bool(getattr(self.config, "ddp_overlap_halves", False)) and lib.wsae_wgrad_parts_supported(handle):
             if getattr(self, "_reserve_set", None) != handle:  # once per ctx
@@ -344,7 +349,7 @@ class SAETrainer:
             N.check(lib.wsae_weight_grads_wire(*args, N.PART_ALL, wire.data_ptr(), wire_dt, st), "wsae_weight_grads_wire")
             ex.run(wire)  # (in stream order: nothing of this step could run beside it)
         scale = ex.finish()  # (RCCL: the compute stream waits for the asynchronous collectives; the host does not)
-        N.check(lib.wsae_grads_unpack_wire(handle, wire.data_ptr(), wire_dt, opt.grads_ext.data_ptr(), 0, nranks, stats, st),
+        N.check(lib.wsae_grads_unpack_wire(handle, wire.data_ptr(), wire_dt, opt.grads_ext.data_ptr(), N.ptr(met), nranks, stats, st),
                 "wsae_grads_unpack_wire")
         return scale
 
