@@ -861,9 +861,15 @@ grad_finish_kernel(const float* __restrict__ slabs, const float* __restrict__ db
                 for (int t = 0; t < TR; ++t) {
                     const int idx = min(c0 + lane + 64 * t, total - 1);  // clamped: unconditional loads
                     const int jr = idx >= nc ? 1 : 0, cc = idx - jr * nc;
+                    if (nsplit == 1) {  // (small batches: one slab - one load, not NS copies of it; a uniform branch)
+                        v[t][0] = nt_load4(base + (jr * NS) * nc + cc);
 #pragma unroll
-                    for (int sp = 0; sp < NS; ++sp)  // splits past nsplit re-read the last one (weight 0)
-                        v[t][sp] = nt_load4(base + (jr * NS + min(sp, nsplit - 1)) * nc + cc);  // (last use of the slabs)
+                        for (int sp = 1; sp < NS; ++sp) v[t][sp] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+#pragma unroll
+                        for (int sp = 0; sp < NS; ++sp)  // splits past nsplit re-read the last one (weight 0)
+                            v[t][sp] = nt_load4(base + (jr * NS + min(sp, nsplit - 1)) * nc + cc);  // (last use of the slabs)
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < TR; ++t) {
